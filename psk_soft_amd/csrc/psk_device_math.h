@@ -1,0 +1,215 @@
+// psk_device_math.h -- gfx950 device arithmetic for the psk_soft hot path.
+//
+// Every function states which reference expression (and which libstdc++ / libgcc routine
+// behind it) it reproduces, with the float / double rounding points of SURVEY.md
+// section 8(a).  The translation unit is built with -ffp-contract=off, so a*b+c below
+// is a rounded product followed by a rounded sum (quirk Q9), never an fma.
+#ifndef PSK_DEVICE_MATH_H
+#define PSK_DEVICE_MATH_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psk {
+
+#define PSK_DEV __device__ __forceinline__
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;  // cpp/psk_soft.h:65  2*M_PI
+constexpr double kPi = 3.14159265358979323846;               // M_PI
+constexpr double kPi4 = 0.78539816339744830962;              // M_PI_4
+
+struct cf32 {
+    float re, im;
+};
+
+// std::norm(complex<float>) (cpp/psk_soft.cpp:448): x*x + y*y in float, unfused.
+PSK_DEV float norm_f(float re, float im)
+{
+    float xx = re * re;
+    float yy = im * im;
+    return xx + yy;
+}
+
+PSK_DEV bool is_nan(float v) { return v != v; }
+PSK_DEV bool is_inf(float v) { return __builtin_fabsf(v) == __builtin_inff(); }
+PSK_DEV bool is_fin(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
+
+// complex<float> multiply = GCC complex multiply (cpp/psk_soft.cpp:474 via pow, :500):
+// (ac-bd, ad+bc); when both parts are NaN, libgcc __mulsc3's C99 Annex G recovery.
+PSK_DEV cf32 cmul_recover(float a, float b, float c, float d, float ac, float bd, float ad, float bc)
+{
+    cf32 r;
+    r.re = ac - bd;
+    r.im = ad + bc;
+    bool recalc = false;
+    if (is_inf(a) || is_inf(b)) {
+        a = __builtin_copysignf(is_inf(a) ? 1.0f : 0.0f, a);
+        b = __builtin_copysignf(is_inf(b) ? 1.0f : 0.0f, b);
+        if (is_nan(c)) c = __builtin_copysignf(0.0f, c);
+        if (is_nan(d)) d = __builtin_copysignf(0.0f, d);
+        recalc = true;
+    }
+    if (is_inf(c) || is_inf(d)) {
+        c = __builtin_copysignf(is_inf(c) ? 1.0f : 0.0f, c);
+        d = __builtin_copysignf(is_inf(d) ? 1.0f : 0.0f, d);
+        if (is_nan(a)) a = __builtin_copysignf(0.0f, a);
+        if (is_nan(b)) b = __builtin_copysignf(0.0f, b);
+        recalc = true;
+    }
+    if (!recalc && (is_inf(ac) || is_inf(bd) || is_inf(ad) || is_inf(bc))) {
+        if (is_nan(a)) a = __builtin_copysignf(0.0f, a);
+        if (is_nan(b)) b = __builtin_copysignf(0.0f, b);
+        if (is_nan(c)) c = __builtin_copysignf(0.0f, c);
+        if (is_nan(d)) d = __builtin_copysignf(0.0f, d);
+        recalc = true;
+    }
+    if (recalc) {
+        r.re = __builtin_inff() * (a * c - b * d);
+        r.im = __builtin_inff() * (a * d + b * c);
+    }
+    return r;
+}
+
+template <bool RECOVER>
+PSK_DEV cf32 cmul(cf32 x, cf32 y)
+{
+    float ac = x.re * y.re, bd = x.im * y.im, ad = x.re * y.im, bc = x.im * y.re;
+    cf32 r;
+    r.re = ac - bd;
+    r.im = ad + bc;
+    if (RECOVER) {
+        if (is_nan(r.re) && is_nan(r.im))
+            r = cmul_recover(x.re, x.im, y.re, y.im, ac, bd, ad, bc);
+    }
+    return r;
+}
+
+// pow(complex<float>, size_t) in gnu++98 = __complex_pow_unsigned (quirk Q6,
+// cpp/psk_soft.cpp:474).  n is wave-uniform.
+template <bool RECOVER>
+PSK_DEV cf32 cpow_uint(cf32 x, unsigned n)
+{
+    cf32 y;
+    if (n % 2) {
+        y = x;
+    } else {
+        y.re = 1.0f;
+        y.im = 0.0f;
+    }
+    while (n >>= 1) {
+        x = cmul<RECOVER>(x, x);
+        if (n % 2)
+            y = cmul<RECOVER>(y, x);
+    }
+    return y;
+}
+
+// complex<float> divide = libgcc __divsc3 as a g++-linked binary resolves it in the oracle
+// image (GCC 12 libgcc_s: quotient formed in double, one rounding per part, then the
+// Annex G recovery) -- cpp/psk_soft.cpp:488, differential decoding only (quirk Q10).
+PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
+{
+    float a = n.re, b = n.im, c = dn.re, d = dn.im;
+    double aa = a, bb = b, cc = c, dd = d;
+    double denom = (cc * cc) + (dd * dd);
+    float x = (float)(((aa * cc) + (bb * dd)) / denom);
+    float y = (float)(((bb * cc) - (aa * dd)) / denom);
+    if (is_nan(x) && is_nan(y)) {
+        if (c == 0.0f && d == 0.0f && (!is_nan(a) || !is_nan(b))) {
+            x = __builtin_copysignf(__builtin_inff(), c) * a;
+            y = __builtin_copysignf(__builtin_inff(), c) * b;
+        } else if ((is_inf(a) || is_inf(b)) && is_fin(c) && is_fin(d)) {
+            a = __builtin_copysignf(is_inf(a) ? 1.0f : 0.0f, a);
+            b = __builtin_copysignf(is_inf(b) ? 1.0f : 0.0f, b);
+            x = __builtin_inff() * (a * c + b * d);
+            y = __builtin_inff() * (b * c - a * d);
+        } else if ((is_inf(c) || is_inf(d)) && is_fin(a) && is_fin(b)) {
+            c = __builtin_copysignf(is_inf(c) ? 1.0f : 0.0f, c);
+            d = __builtin_copysignf(is_inf(d) ? 1.0f : 0.0f, d);
+            x = 0.0f * (a * c + b * d);
+            y = 0.0f * (b * c - a * d);
+        }
+    }
+    cf32 r;
+    r.re = x;
+    r.im = y;
+    return r;
+}
+
+// (long) of a double as x86-64 cvttsd2si does it (cpp/psk_soft.cpp:477, 598)
+PSK_DEV long long to_long_x86(double v)
+{
+    if (!(v < 9223372036854775808.0) || v < -9223372036854775808.0)  // also NaN
+        return (long long)0x8000000000000000ull;
+    return (long long)v;
+}
+
+// numWraps = round((phaseEstimate-thisPhase)/M_2PI)  (cpp/psk_soft.cpp:477)
+PSK_DEV long long unwrap_count(float phaseEstimate, double thisPhase)
+{
+    return to_long_x86(__builtin_round(((double)phaseEstimate - thisPhase) / kTwoPi));
+}
+
+// LinearFit::calculateDenominator (cpp/psk_soft.cpp:176-185): C pow(double,double) on
+// exactly representable arguments is exact, so p*p*p == pow(p,3) and xd*xd == pow(xd,2).
+PSK_DEV void fit_denominator(float xdelta, unsigned pts, float &denominator, float &xAvg)
+{
+    if (pts <= 1)
+        return;
+    unsigned pts_m_1 = pts - 1;
+    double p = (double)pts_m_1;
+    double p2 = p * p;
+    double p3 = p2 * p;
+    double poly = p3 / 3.0 + p2 / 2.0 + p / 6.0 - p2 * (double)pts / 4.0;
+    double xd = (double)xdelta;
+    denominator = (float)((xd * xd) * poly);
+    xAvg = xdelta * (float)pts_m_1 / 2;
+}
+
+// LinearFit::calculateFit (cpp/psk_soft.cpp:135-174) for pts > 1
+PSK_DEV float fit_value(double ySum, double xySum, float xdelta, unsigned pts, float denominator, float xAvg,
+                        float &m_out, float &b_out)
+{
+    unsigned pts_m_1 = pts - 1;
+    float half_span = xdelta * (float)pts_m_1 / 2;
+    float m = (float)((xySum - (double)half_span * ySum) / (double)denominator);
+    float mx = m * xAvg;
+    float b = (float)(ySum / (double)pts - (double)mx);
+    float xVal = xdelta * (float)pts_m_1;
+    float mxv = m * xVal;
+    m_out = m;
+    b_out = b;
+    return mxv + b;
+}
+
+// abs(phaseEstimate) > wrapValue with ::abs(int) (quirk Q5, cpp/psk_soft.cpp:596)
+PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
+{
+    int asInt;
+    if (!(phaseEstimate < 2147483648.0f) || phaseEstimate < -2147483648.0f)
+        asInt = (int)0x80000000;
+    else
+        asInt = (int)phaseEstimate;
+    if (asInt != (int)0x80000000 && asInt < 0)
+        asInt = -asInt;
+    return (float)asInt > wrapValue;
+}
+
+// 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
+{
+    float theta = atan2f(c_im, c_re);
+    float softsym = (float)((double)theta / kPi * 4);
+    if ((double)softsym < -.5)
+        softsym = softsym + 8.0f;
+    double r = __builtin_round((double)softsym);
+    int asInt;
+    if (!(r < 2147483648.0) || r < -2147483648.0)
+        asInt = (int)0x80000000;
+    else
+        asInt = (int)r;
+    return (unsigned short)(unsigned)asInt;
+}
+
+}  // namespace psk
+#endif

@@ -1,0 +1,76 @@
+// psk_plan.h -- the call plan handed from the host control plane to the device kernels.
+//
+// Everything in serviceFunction() that steers the loop but does not depend on sample
+// VALUES -- property snapshot, reset flags, deque lengths, symbol clock, how many symbols
+// the call emits (reference cpp/psk_soft.cpp:365-426, 454-457, 568-590) -- is resolved
+// on the host (psk_ctl.h) and frozen into one ChanPlan per channel per call.  The
+// kernels (psk_kernels.hip) do the arithmetic.  Plain PODs shared by host and device.
+#ifndef PSK_PLAN_H
+#define PSK_PLAN_H
+
+#include <stdint.h>
+
+namespace psk {
+
+enum PlanMode : uint32_t {
+    PLAN_SKIP = 0,    // no packet / real data / nothing to do on the device
+    PLAN_FAST = 1,    // wave-scan kernel
+    PLAN_SEQ = 2,     // reference-order kernel, regular window mode (samplesPerBaud > 1)
+    PLAN_SEQ_S1 = 3,  // reference-order kernel, samplesPerBaud == 1 emitting (numAvg == 0)
+};
+
+enum LfFlags : uint32_t {
+    LF_RECOMPUTE = 1u,  // LinearFit::reset() ran: sums rebuilt from yvals, count = 0 (cpp/psk_soft.cpp:110-122)
+};
+
+constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582
+
+struct ChanPlan {
+    // data (device pointers)
+    const float *in;   // packet: interleaved I,Q
+    float *soft;
+    int16_t *bits;
+    float *phase;
+    int16_t *sidx;
+    uint64_t n_in;     // complex samples in the packet
+    uint64_t n_out;    // symbols this call emits
+    // geometry
+    uint32_t mode;     // PlanMode
+    uint32_t S;        // samplesPerBaud snapshot       (cpp/psk_soft.cpp:376)
+    uint32_t A;        // numAvg snapshot               (:377)
+    uint32_t M;        // constelationSize snapshot     (:378)
+    uint32_t bpb;      // bitsPerBaud                   (:384-390)
+    uint32_t diff;     // differentialDecoding
+    uint32_t ring_len0;  // samples.size() after the prologue (after resyncEnergy's trim), device-resident
+    uint32_t ring_len1;  // samples.size() at return (clipped to the ring capacity)
+    uint32_t ring_src;   // which of the two ring buffers holds the samples now
+    // LinearFit control state (host-mirrored)
+    uint32_t lf_flags;
+    uint32_t lf_n;       // LinearFit::n after the prologue
+    uint32_t lf_head;    // circular yvals buffer: index of the oldest value
+    uint32_t lf_len0;    // yvals.size() after the prologue
+    uint32_t lf_count0;  // LinearFit::count at the first next()
+    uint32_t count0;     // psk_soft_i::count at loop start
+    float lf_xdelta;     // LinearFit::xdelta after the prologue
+};
+
+// Data-dependent per-channel state that lives in HBM between calls.
+struct ChanState {
+    double lf_ySum;       // LinearFit::ySum
+    double lf_xySum;      // LinearFit::xySum
+    float last_re;        // psk_soft_i::last
+    float last_im;
+    float phaseEstimate;  // psk_soft_i::phaseEstimate
+    float lf_den;         // LinearFit::denominator
+    float lf_xavg;        // LinearFit::xAvg
+    float lf_m;           // LinearFit::m, b (write-only in the reference; kept for completeness)
+    float lf_b;
+    uint32_t guard;       // set by the wave-scan kernel when it hands the call to the reference-order kernel
+    // statistics of the last call
+    uint32_t stat_blocks;
+    uint32_t stat_extra;
+    uint32_t pad[2];
+};
+
+}  // namespace psk
+#endif

@@ -1,0 +1,126 @@
+"""Host logic of the C-ABI library (no GPU): the control plane that mirrors the non-data
+state of psk_soft_i (psk_soft_amd/csrc/psk_ctl.h) must agree, call by call, with the
+oracle's counters -- output counts, pushSRI decisions and SRI xdeltas, warning counts,
+samples.size(), index and yvals.size() -- over random sequences of property changes,
+resets, queue flushes, real-data packets and ragged packet sizes (reference
+cpp/psk_soft.cpp:353-426, 454-457, 568-590, 619-651)."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from psk_soft_amd import lib as pl
+
+
+def _mk(oracle_mod):
+    h = pl.Handle(1, device=pl.DEVICE_NONE, max_window_samples=1 << 16, max_phase_avg=4096)
+    o = oracle_mod.OracleComponent()
+    return h, o
+
+
+def _set(h, o, name, value):
+    h.configure(0, [{name: value}])
+    setattr(o, name, value)
+
+
+def _same(a, b):
+    return a == b or (isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_call_sequences(oracle_mod, seed):
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    h, o = _mk(oracle_mod)
+    S_choices = [1, 2, 3, 4, 5, 8, 10, 16, 7]
+    A_choices = [0, 1, 2, 5, 20, 100]
+    M_choices = [2, 4, 8, 16, 3, 1]
+    n_choices = [1, 2, 5, 50, 200]
+    xd_choices = [0.01, 1.0, 0.5, 1e-6]
+    for call in range(120):
+        # property traffic between calls
+        for _ in range(rng.choice([0, 0, 0, 1, 2])):
+            what = rng.choice(["S", "A", "M", "n", "diff", "reset"])
+            if what == "S":
+                _set(h, o, "samplesPerBaud", rng.choice(S_choices))
+            elif what == "A":
+                _set(h, o, "numAvg", rng.choice(A_choices))
+            elif what == "M":
+                _set(h, o, "constelationSize", rng.choice(M_choices))
+            elif what == "n":
+                _set(h, o, "phaseAvg", rng.choice(n_choices))
+            elif what == "diff":
+                _set(h, o, "differentialDecoding", rng.choice([0, 1]))
+            else:
+                _set(h, o, "resetState", 1)
+        n_complex = rng.choice([0, 1, 3, 7, 64, 100, 777, 1000, 2500])
+        odd = rng.random() < 0.1
+        n_floats = 2 * n_complex + (1 if odd else 0)
+        data = nrng.standard_normal(n_floats).astype(np.float32)
+        xdelta = rng.choice(xd_choices) if rng.random() < 0.2 or call == 0 else xdelta  # noqa: F821
+        mode = 0 if rng.random() < 0.05 else 1
+        sri = call == 0 or rng.random() < 0.1
+        flushed = rng.random() < 0.05
+        ro = o.service(data, xdelta, mode=mode, sriChanged=sri, inputQueueFlushed=flushed)
+        rg = h.plan_only(0, [dict(n_floats=n_floats, xdelta=xdelta, mode=mode, sriChanged=sri, inputQueueFlushed=flushed)])[0]
+        ctx = "seed %d call %d" % (seed, call)
+        assert rg["ret"] == ro.ret, ctx
+        assert rg["n_symbols"] == ro.phase.size, ctx
+        assert 2 * rg["n_symbols"] == ro.soft.size, ctx
+        assert rg["n_bits"] == ro.bits.size, ctx
+        assert rg["n_sampleIndex"] == ro.index.size, ctx
+        assert rg["sri_pushed"] == ro.sri_pushed, ctx
+        if ro.sri_pushed:
+            assert _same(rg["sri_soft_xdelta"], ro.sri_soft_xdelta), ctx
+            assert _same(rg["sri_bits_xdelta"], ro.sri_bits_xdelta), ctx
+        assert rg["n_warn"] == ro.n_warn, ctx
+        pk = h.peek(0)
+        assert pk["ring_len"] == o.ring_size, ctx
+        assert pk["index"] == o.index, ctx
+        assert pk["fit_len"] == o.fit_history().size, ctx
+
+
+def test_no_packet_is_noop(oracle_mod):
+    h, _ = _mk(oracle_mod)
+    r = h.plan_only(0, [None])[0]
+    assert r["ret"] == pl.NOOP and r["n_symbols"] == 0
+
+
+def test_unsupported_and_limits():
+    h = pl.Handle(1, device=pl.DEVICE_NONE, max_window_samples=1000, max_phase_avg=64)
+    with pytest.raises(pl.PskSoftError) as e:
+        h.configure(0, [{"samplesPerBaud": 8, "numAvg": 200}])
+    assert e.value.status == 4  # PSK_SOFT_ERR_LIMIT
+    with pytest.raises(pl.PskSoftError):
+        h.configure(0, [{"phaseAvg": 100}])
+    h.configure(0, [{"samplesPerBaud": 0}])
+    with pytest.raises(pl.PskSoftError) as e:
+        h.plan_only(0, [dict(n_floats=16, xdelta=0.01)])
+    assert e.value.status == 5  # PSK_SOFT_ERR_UNSUPPORTED (undefined in the reference)
+    # a refused call leaves the channel untouched
+    h.configure(0, [{"samplesPerBaud": 8, "numAvg": 100}])
+    assert h.peek(0)["ring_len"] == 0
+
+
+def test_abi_exports_every_declared_symbol():
+    L = pl.load()
+    for name in pl.EXPORTS:
+        assert hasattr(L, name), name
+    assert L.psk_soft_abi_version() == 1
+    import os
+    import re
+
+    hdr = open(os.path.join(os.path.dirname(pl._HERE), "include", "psk_soft_hip.h")).read()
+    declared = set(re.findall(r"\b(psk_soft_[a-z_]+)\s*\(", hdr))
+    assert declared == set(pl.EXPORTS), declared ^ set(pl.EXPORTS)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pl.PskSoftError) as e:
+        pl.Handle(1, device=0)
+    assert e.value.status == 2  # PSK_SOFT_ERR_NO_DEVICE: no silent CPU path
