@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the psk_soft hot path on MI355X.
+
+Metric (BASELINE.json): complex IQ Msamples/s, QPSK, 8 samples/baud, 4096 channels per
+GPU, inputs and outputs resident in HBM.  A "step" is one serviceFunction() body
+(psk_soft_process_device) over one packet of every channel.  Weak scaling: every rank
+(= GPU) owns its own 4096 channels -- channels are independent,
+so there is no data-path collective; torch.distributed is used only for the barrier
+and the max-over-ranks of the elapsed time.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line on rank 0, with `roofline` (HBM read roofline of the wave-scan
+kernel) and `cpu_baseline` (the CPU oracle timed on this node's host cores, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
+    ap.add_argument("--nsamp", type=int, default=1 << 18, help="complex samples per channel per step")
+    ap.add_argument("--M", type=int, default=4)
+    ap.add_argument("--S", type=int, default=8)
+    ap.add_argument("--numAvg", type=int, default=100)
+    ap.add_argument("--phaseAvg", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall seconds of the CPU baseline sample")
+    ap.add_argument("--check", action="store_true", help="verify a few channels against the oracle after the run")
+    return ap.parse_args()
+
+
+def cpu_baseline(iq_host, M, S, A, n, wall_budget):
+    """Time the CPU oracle (kind 'port': oracle/psk_soft_oracle.c, one psk_soft_i per
+    channel) on all host cores over a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import pyoracle as po
+
+    po.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("PSK_BENCH_CPU_THREADS", "16")))  # the 1-GPU box's CPU share is 16 cores
+    n_ch, n_fl = iq_host.shape
+    n_complex = n_fl // 2
+
+    def work(tid):
+        done = 0
+        comps = {}
+        t_end = time.perf_counter() + wall_budget
+        c = tid
+        while time.perf_counter() < t_end:
+            ch = c % n_ch
+            comp = comps.get(ch)
+            if comp is None:
+                comp = po.OracleComponent()
+                comp.samplesPerBaud = S
+                comp.constelationSize = M
+                comp.numAvg = A
+                comp.phaseAvg = n
+                comps[ch] = comp
+            comp.service(iq_host[ch], 0.01, sriChanged=(done == 0))
+            done += n_complex
+            c += cores
+        return done
+
+    # one untimed packet per thread to page everything in
+    warm = po.OracleComponent()
+    warm.samplesPerBaud = S
+    warm.constelationSize = M
+    warm.numAvg = A
+    warm.service(iq_host[0], 0.01, sriChanged=True)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": total / dt / 1e6,
+        "unit": "complex IQ Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d-sample packets of %d distinct channels of the same workload, %d threads, %.1f s wall (%.0f Msamples)"
+        % (n_complex, n_ch, cores, dt, total / 1e6),
+    }
+
+
+def main():
+    a = parse()
+    import torch
+
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channels_torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    C, N, S, M = a.channels, a.nsamp, a.S, a.M
+    bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
+    h = pl.Handle(C, device=local_rank, max_window_samples=max(16384, S * a.numAvg), max_phase_avg=max(512, a.phaseAvg))
+    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)
+
+    # synthetic section-8(d) workload, generated in HBM; every rank draws its own channels
+    iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank)
+    cap = N // S + 2
+    soft = torch.empty((C, 2 * cap), dtype=torch.float32, device=dev)
+    phase = torch.empty((C, cap), dtype=torch.float32, device=dev)
+    sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)
+    bits = torch.empty((C, max(bpb, 1) * cap), dtype=torch.int16, device=dev)
+    pk = (pl.Packet * C)()
+    out = (pl.Output * C)()
+    for c in range(C):
+        pk[c].data = iq[c].data_ptr()
+        pk[c].n_floats = 2 * N
+        pk[c].sri_xdelta = 0.01
+        pk[c].sri_mode = 1
+        pk[c].sriChanged = 0
+        pk[c].present = 1
+        out[c].soft = soft[c].data_ptr()
+        out[c].bits = bits[c].data_ptr()
+        out[c].phase = phase[c].data_ptr()
+        out[c].sampleIndex = sidx[c].data_ptr()
+        out[c].cap_symbols = cap
+    # a dedicated (non-null) stream: the library is handed its raw hipStream_t, and the HIP
+    # events below are recorded on that same stream
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def step():
+        h.process_device(0, pk, out, stream=stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # device time of one launch set (plan upload + wave-scan kernel + reference-order kernel),
+    # HIP events on the stream the kernels run on
+    dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    st = h.stats()
+    n_out = int(out[0].n_symbols)
+
+    samples_per_step = C * N * world
+    value = samples_per_step * a.steps / elapsed / 1e6
+    alg_read_bytes = 8.0 * C * N  # 8 B per complex input sample
+    alg_write_bytes = C * n_out * (8 + 4 + 2 + 2 * bpb)
+    achieved = alg_read_bytes / (dev_ms_avg * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "complex IQ Msamples/s, QPSK 8 sps, 4096 ch; % HBM roofline at 1/2/4/8 GPUs",
+        "value": value,
+        "unit": "complex IQ Msamples/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s, samplesPerBaud=%d, %d channels per GPU x %d complex samples per step, numAvg=%d, phaseAvg=%d, "
+            "inputs/outputs resident in HBM" % ({2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, C, N, a.numAvg, a.phaseAvg),
+            "channels_per_gpu": C,
+            "samples_per_channel_per_step": N,
+            "symbols_out_per_channel_per_step": n_out,
+            "parallelism": "channels sharded, %d per GPU, no collective" % C,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "psk_fast_kernel<%d>" % S,
+            "algorithmic_read_bytes_per_launch": alg_read_bytes,
+            "algorithmic_write_bytes_per_launch": alg_write_bytes,
+            "launch_ms_avg": dev_ms_avg,
+            "launch_ms_min": dev_ms[0],
+        },
+        "kernel_stats": st,
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        n_host = min(C, 64)
+        iq_host = iq[:n_host].cpu().numpy()
+        res["cpu_baseline"] = cpu_baseline(iq_host, M, S, a.numAvg, a.phaseAvg, a.cpu_seconds)
+        res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+
+    if a.check and rank == 0:
+        from oracle import pyoracle as po
+
+        # replay channel 0 and C-1 through the oracle with the same packetisation
+        import numpy as np
+
+        worst = 0.0
+        for c in (0, C - 1):
+            comp = po.OracleComponent()
+            comp.samplesPerBaud = S
+            comp.constelationSize = M
+            comp.numAvg = a.numAvg
+            comp.phaseAvg = a.phaseAvg
+            x = iq[c].cpu().numpy()
+            r = None
+            for k in range(a.warmup + a.steps):
+                r = comp.service(x, 0.01, sriChanged=False)
+            gs = soft[c, : 2 * n_out].cpu().numpy()
+            gb = bits[c, : bpb * n_out].cpu().numpy()
+            gi = sidx[c, :n_out].cpu().numpy()
+            assert np.array_equal(gb, r.bits) and np.array_equal(gi, r.index), "bit/index mismatch on channel %d" % c
+            worst = max(worst, float(np.abs(gs - r.soft).max() / np.abs(r.soft).max()))
+        res["check"] = {"channels": [0, C - 1], "bits_index_exact": True, "soft_max_rel_err": worst}
+
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
