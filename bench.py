@@ -166,9 +166,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from psk_soft_amd.distributed import max_over_ranks
+
+        elapsed = max_over_ranks(elapsed, dist, dev)
     # device time of one launch set (plan upload + wave-scan kernel + reference-order kernel),
     # HIP events on the stream the kernels run on
     dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
