@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "psk_libm.h"
+
 namespace psk {
 
 #define PSK_DEV __device__ __forceinline__
@@ -17,6 +19,7 @@ namespace psk {
 constexpr double kTwoPi = 6.283185307179586476925286766559;  // cpp/psk_soft.h:65  2*M_PI
 constexpr double kPi = 3.14159265358979323846;               // M_PI
 constexpr double kPi4 = 0.78539816339744830962;              // M_PI_4
+constexpr double kInvTwoPi = 1.0 / kTwoPi;                   // correctly rounded 1/(2*pi), for lm_div_known
 
 struct cf32 {
     float re, im;
@@ -147,7 +150,8 @@ PSK_DEV long long to_long_x86(double v)
 // numWraps = round((phaseEstimate-thisPhase)/M_2PI)  (cpp/psk_soft.cpp:477)
 PSK_DEV long long unwrap_count(float phaseEstimate, double thisPhase)
 {
-    return to_long_x86(__builtin_round(((double)phaseEstimate - thisPhase) / kTwoPi));
+    // the quotient is bit-identical to the IEEE division (lm_div_known)
+    return to_long_x86(__builtin_round(lm_div_known((double)phaseEstimate - thisPhase, kTwoPi, kInvTwoPi)));
 }
 
 // LinearFit::calculateDenominator (cpp/psk_soft.cpp:176-185): C pow(double,double) on
@@ -182,6 +186,23 @@ PSK_DEV float fit_value(double ySum, double xySum, float xdelta, unsigned pts, f
     return mxv + b;
 }
 
+// calculateFit with the two divisors' reciprocals precomputed (steady state: they are
+// wave-uniform): rden = 1.0/(double)denominator, rpts = 1.0/(double)pts
+PSK_DEV float fit_value_known(double ySum, double xySum, float xdelta, unsigned pts, float denominator, float xAvg,
+                              double rden, double rpts, float &m_out, float &b_out)
+{
+    unsigned pts_m_1 = pts - 1;
+    float half_span = xdelta * (float)pts_m_1 / 2;
+    float m = (float)lm_div_known(xySum - (double)half_span * ySum, (double)denominator, rden);
+    float mx = m * xAvg;
+    float b = (float)(lm_div_known(ySum, (double)pts, rpts) - (double)mx);
+    float xVal = xdelta * (float)pts_m_1;
+    float mxv = m * xVal;
+    m_out = m;
+    b_out = b;
+    return mxv + b;
+}
+
 // abs(phaseEstimate) > wrapValue with ::abs(int) (quirk Q5, cpp/psk_soft.cpp:596)
 PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 {
@@ -198,7 +219,7 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 // 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
 PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
 {
-    float theta = atan2f(c_im, c_re);
+    float theta = lm_atan2f(c_im, c_re);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)
         softsym = softsym + 8.0f;

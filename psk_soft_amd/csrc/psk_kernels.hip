@@ -237,6 +237,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
     float den_s = cy.den, xavg_s = cy.xavg;
     if (n > 1)
         fit_denominator(xd, n, den_s, xavg_s);
+    const double rden_s = 1.0 / (double)den_s, rpts_s = 1.0 / (double)n;
 
     const uint64_t n_blocks = (n_out + kWave - 1) / kWave;
     for (uint64_t c = 0; c < n_blocks; c++) {
@@ -281,7 +282,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
         cf32 pw = cpow_uint<false>(s, M);
         if (valid && !(is_fin(pw.re) && is_fin(pw.im)))
             cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-        const double rawd = (double)atan2f(pw.im, pw.re);
+        const double rawd = (double)lm_atan2f(pw.im, pw.re);
 
         // ---- feedback unwrap + LinearFit::next, 64 symbols at a time ----
         const uint32_t q0 = cy.q;
@@ -298,7 +299,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
         {
             double raw_prev = wave_up1(rawd, rawd);
             int delta = (lane == 0) ? (int)unwrap_count(cy.est, rawd)
-                                    : (int)to_long_x86(__builtin_round((raw_prev - rawd) / kTwoPi));
+                                    : (int)to_long_x86(__builtin_round((raw_prev - rawd) * kInvTwoPi));
             delta = valid ? delta : 0;
             w = wave_scan_i32(delta);
         }
@@ -322,7 +323,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             double cterm = (double)t - (steady ? (double)xd * ySumP : 0.0);  // :72 and :78
             cterm = valid ? cterm : 0.0;
             xySum_l = cy.xySum + wave_scan_f64(cterm);
-            if (pts > 1) {
+            if (q0 >= n) {  // steady state: both divisors are wave-uniform
+                est = fit_value_known(ySum_l, xySum_l, xd, n, den_s, xavg_s, rden_s, rpts_s, m_l, b_l);
+            } else if (pts > 1) {
                 est = fit_value(ySum_l, xySum_l, xd, pts, den_l, xavg_l, m_l, b_l);
             } else {  // :164-171, a single point: b = yvals.back()
                 m_l = 0.0f;
@@ -357,7 +360,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
         if (M == 4)
             phaseCorrection = (float)((double)phaseCorrection + kPi4);
         float sn, cs;
-        sincosf(phaseCorrection, &sn, &cs);
+        lm_sincosf(phaseCorrection, &sn, &cs);
         cf32 ph;
         ph.re = 1.0f * cs;
         ph.im = 1.0f * sn;
@@ -628,7 +631,7 @@ __device__ void seq_emit_symbol(SeqEmit &E, cf32 sample, int sampleIndex, bool h
     if (have_index && p.sidx)
         p.sidx[i] = (int16_t)(unsigned short)sampleIndex;
     cf32 pw = cpow_uint<true>(sample, p.M);
-    double thisPhase = (double)atan2f(pw.im, pw.re);
+    double thisPhase = (double)lm_atan2f(pw.im, pw.re);
     long long numWraps = unwrap_count(E.pe, thisPhase);
     thisPhase += (double)numWraps * kTwoPi;
     E.pe = E.fit.next((float)thisPhase);
@@ -644,9 +647,11 @@ __device__ void seq_emit_symbol(SeqEmit &E, cf32 sample, int sampleIndex, bool h
     }
     if (p.M == 4)
         phaseCorrection = (float)((double)phaseCorrection + kPi4);
+    float sn, cs;
+    lm_sincosf(phaseCorrection, &sn, &cs);
     cf32 ph;
-    ph.re = 1.0f * cosf(phaseCorrection);
-    ph.im = 1.0f * sinf(phaseCorrection);
+    ph.re = 1.0f * cs;
+    ph.im = 1.0f * sn;
     cf32 corr = cmul<true>(sample, ph);
     if (p.soft) {
         p.soft[2 * i] = corr.re;

@@ -1,0 +1,259 @@
+// psk_libm.h -- the three libm functions of the hot path, restated so that the GPU returns the
+// same floats as the reference's CPU build does.
+//
+// The reference calls, through libstdc++'s std::arg and std::polar,
+//     atan2f   reference cpp/psk_soft.cpp:474 (raw phase) and :547 (8-PSK slicing)
+//     cosf, sinf  reference cpp/psk_soft.cpp:499 (de-rotation phasor)
+// of glibc 2.35 (third-party, not in /root/reference; pinned version = the oracle image's).
+// Restated here from the published algorithms:
+//   * atan2f / atanf: the fdlibm single-precision routines glibc 2.35 ships
+//     (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c): argument reduction to one of five
+//     ranges, an 11-term odd polynomial evaluated in float as two interleaved Horner chains,
+//     hi/lo table recombination.  All float operations, unfused.
+//   * sinf / cosf: the ARM "optimized routines" implementation glibc 2.35 ships
+//     (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h): reduction and polynomial in
+//     double; x86-64 hosts with FMA run the ifunc variant built with contraction, which the
+//     explicit fma() calls below reproduce.
+// tests/test_libm_pin.py compiles this header for the host and checks all three functions
+// bit-for-bit against the oracle image's libm (10^8 arguments, including every special
+// range), so device results equal the oracle's wherever the arguments are equal.
+//
+// The header is host/device neutral: PSK_HD expands to __host__ __device__ under hipcc.
+#ifndef PSK_LIBM_H
+#define PSK_LIBM_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PSK_HD __host__ __device__ __forceinline__
+#else
+#define PSK_HD static inline
+#endif
+
+namespace psk {
+
+PSK_HD uint32_t lm_asuint(float f) { return __builtin_bit_cast(uint32_t, f); }
+PSK_HD float lm_asfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---------------------------------------------------------------------------------
+// atanf / atan2f (fdlibm float)
+// ---------------------------------------------------------------------------------
+PSK_HD float lm_atanf(float x)
+{
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)lm_asuint(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25
+        if (ix > 0x7f800000)
+            return x + x;  // NaN
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    // argument reduction: one division whatever the range (the reference code has one per branch)
+    const float ax = __builtin_fabsf(x);
+    float num, den, hi, lo;
+    int id;
+    if (ix < 0x3ee00000) {  // |x| < 0.4375
+        if (ix < 0x31000000)  // |x| < 2^-29
+            return x;
+        id = -1;
+        num = x;
+        den = 1.0f;
+        hi = 0.0f;
+        lo = 0.0f;
+    } else if (ix < 0x3f300000) {  // 7/16 <= |x| < 11/16
+        id = 0;
+        num = 2.0f * ax - 1.0f;
+        den = 2.0f + ax;
+        hi = hi0;
+        lo = lo0;
+    } else if (ix < 0x3f980000) {  // 11/16 <= |x| < 19/16
+        id = 1;
+        num = ax - 1.0f;
+        den = ax + 1.0f;
+        hi = hi1;
+        lo = lo1;
+    } else if (ix < 0x401c0000) {  // |x| < 2.4375
+        id = 2;
+        num = ax - 1.5f;
+        den = 1.0f + 1.5f * ax;
+        hi = hi2;
+        lo = lo2;
+    } else {
+        id = 3;
+        num = -1.0f;
+        den = ax;
+        hi = hi3;
+        lo = lo3;
+    }
+    const float t = (id < 0) ? num : num / den;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0)
+        return t - t * (s1 + s2);
+    const float r = hi - ((t * (s1 + s2) - lo) - t);
+    return hx < 0 ? -r : r;
+}
+
+PSK_HD float lm_atan2f(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+                pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)lm_asuint(x), hy = (int32_t)lm_asuint(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000)
+        return x + y;  // NaN
+    if (hx == 0x3f800000)
+        return lm_atanf(y);  // x == 1.0
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);  // 2*sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+        case 0:
+        case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (ix == 0)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = lm_atanf(__builtin_fabsf(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return lm_asfloat(lm_asuint(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sinf / cosf (glibc 2.35 flt-32, FMA variant), both from one range reduction
+// ---------------------------------------------------------------------------------
+PSK_HD uint32_t lm_abstop12(float x) { return (lm_asuint(x) >> 20) & 0x7ff; }
+
+// sinf_poly of sincosf.h: n even -> sine polynomial, n odd -> cosine polynomial;
+// neg selects the second table entry (cosine coefficients negated)
+PSK_HD float lm_sincos_poly(double x, double x2, bool neg, int n)
+{
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = __builtin_fma(x2, S3, S2);
+        double x7 = x3 * x2;
+        double s = __builtin_fma(x3, S1, x);
+        return (float)__builtin_fma(x7, s1, s);
+    }
+    const double sg = neg ? -1.0 : 1.0;
+    double x4 = x2 * x2;
+    double c2 = __builtin_fma(x2, sg * C4, sg * C3);
+    double c1 = __builtin_fma(x2, sg * C1, sg * C0);
+    double x6 = x4 * x2;
+    double c = __builtin_fma(x4, sg * C2, c1);
+    return (float)__builtin_fma(x6, c2, c);
+}
+
+// *sp = sinf(y), *cp = cosf(y)
+PSK_HD void lm_sincosf(float y, float *sp, float *cp)
+{
+    const double HPI_INV = 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+    const double HPI = 0x1.921FB54442D18p0;        // pi/2
+    const double x = (double)y;
+    const uint32_t top = lm_abstop12(y);
+    if (top < lm_abstop12(0x1.921FB6p-1f)) {  // |y| < pi/4
+        if (top < lm_abstop12(0x1p-12f)) {
+            *sp = y;
+            *cp = 1.0f;
+            return;
+        }
+        const double x2 = x * x;
+        *sp = lm_sincos_poly(x, x2, false, 0);
+        *cp = lm_sincos_poly(x, x2, false, 1);
+        return;
+    }
+    int n, q;
+    double xr;
+    if (top < lm_abstop12(120.0f)) {  // reduce_fast
+        double r = x * HPI_INV;
+        n = ((int32_t)r + 0x800000) >> 24;
+        xr = __builtin_fma(-(double)n, HPI, x);
+        q = n;
+    } else if (top < lm_abstop12(__builtin_inff())) {  // reduce_large: 192 bits of 4/pi
+        const uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
+                                       0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+                                       0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
+                                       0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+        uint32_t xi = lm_asuint(y);
+        const int sign = (int)(xi >> 31);
+        const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+        const int shift = (int)((xi >> 23) & 7);
+        xi = (xi & 0xffffff) | 0x800000;
+        xi <<= shift;
+        uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+        uint64_t res1 = (uint64_t)xi * arr[4];
+        uint64_t res2 = (uint64_t)xi * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+        res0 -= nn << 62;
+        xr = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+        n = (int)nn;
+        q = n + sign;
+    } else {  // inf / NaN -> NaN
+        *sp = y - y;
+        *cp = y - y;
+        return;
+    }
+    const double s = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;  // sign[q & 3] = {1,-1,-1,1}
+    const bool neg = (q & 2) != 0;
+    const double xs = xr * s, x2 = xr * xr;
+    *sp = lm_sincos_poly(xs, x2, neg, n);
+    *cp = lm_sincos_poly(xs, x2, neg, n ^ 1);
+}
+
+// ---------------------------------------------------------------------------------
+// a / b for a divisor whose correctly rounded reciprocal rb = 1.0 / b is known
+// (Markstein: q = RN(a*rb), r = a - q*b exactly by fma, RN(q + r*rb) is the correctly
+// rounded quotient; the excluded case, a divisor significand of all ones, cannot occur for
+// the divisors used here: 2*pi, float-valued doubles and small integers).  Bit-identical to
+// the reference's IEEE double divisions at cpp/psk_soft.cpp:157-158 and :477.
+// ---------------------------------------------------------------------------------
+PSK_HD double lm_div_known(double a, double b, double rb)
+{
+    double q = a * rb;
+    double r = __builtin_fma(-q, b, a);
+    return __builtin_fma(r, rb, q);
+}
+
+}  // namespace psk
+#endif
