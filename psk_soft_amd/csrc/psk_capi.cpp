@@ -19,8 +19,8 @@
 #include "psk_soft_hip.h"
 
 namespace psk {
-hipError_t launch_fast(int S, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
-                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
+hipError_t launch_fast(int S, int H, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
+                       float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 }  // namespace psk
@@ -43,7 +43,7 @@ psk_soft_status fail(psk_soft_status st, const std::string &msg)
     } while (0)
 
 constexpr int kPlanSlots = 4;
-constexpr uint32_t kFastFitMax = 448;  // LDS y ring of the wave-scan kernel: 512 - 64
+constexpr uint32_t kFastFitMax = 384;  // LDS y ring of the wave-scan kernel: 512 - 128
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2, 4, 5, 8, 10, 16};
 
@@ -254,9 +254,9 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (!h->dry && plans[i].mode != psk::PLAN_SKIP) {
             const psk::ChanPlan &p = plans[i];
             if ((p.n_in && !p.in) || ((uintptr_t)p.in & 7u) || ((uintptr_t)p.soft & 7u) || ((uintptr_t)p.bits & 3u) ||
-                ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 1u))
+                ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 3u))
                 return fail(PSK_SOFT_ERR_INVALID_ARG,
-                            "psk_soft_process: packet data must be 8-byte aligned, soft 8, bits 4, phase 4, sampleIndex 2");
+                            "psk_soft_process: packet data must be 8-byte aligned, soft 8, bits 4, phase 4, sampleIndex 4");
         }
     }
     for (uint32_t i = 0; i < nch; i++) {
@@ -268,7 +268,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
 
     // which kernels does this batch need?
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
-    bool need_S[17] = {};
+    bool need_SH[17][5] = {};
     for (uint32_t i = 0; i < nch; i++) {
         const psk::ChanPlan &p = plans[i];
         if (p.mode == psk::PLAN_SKIP)
@@ -277,7 +277,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (p.mode == psk::PLAN_FAST) {
             if (p.n_out) {
                 any_emit = true;
-                need_S[p.S] = true;
+                need_SH[p.S][(p.A + 127u) / 128u] = true;
             } else {
                 any_quiet = true;
             }
@@ -298,12 +298,13 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
                            stream));
     if (any_quiet)
-        PSK_HIP(psk::launch_fast(0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+        PSK_HIP(psk::launch_fast(0, 1, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                  h->lim.fit_cap, stream));
     for (int S : kFastS)
-        if (need_S[S])
-            PSK_HIP(psk::launch_fast(S, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                     h->lim.fit_cap, stream));
+        for (int H = 1; H <= 4; H++)
+            if (need_SH[S][H])
+                PSK_HIP(psk::launch_fast(S, H, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap,
+                                         h->d_yv, h->lim.fit_cap, stream));
     if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
         PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                 h->lim.fit_cap, stream));
@@ -323,7 +324,7 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
     }
     PSK_HIP(hipSetDevice(h->device));
     const uint64_t in_cap = h->user.max_packet_complex;
-    const uint64_t out_cap = in_cap + 2;
+    const uint64_t out_cap = (in_cap + 3) & ~1ull;  // even: every channel's rows stay 4-byte aligned
     if (!h->d_in) {
         const size_t n = h->nch;
         PSK_HIP(hipMalloc((void **)&h->d_in, sizeof(float) * 2 * in_cap * n));

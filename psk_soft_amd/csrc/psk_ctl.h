@@ -73,6 +73,9 @@ struct Limits {
     bool force_seq;
 };
 
+// instantiations of the wave-scan kernel: samplesPerBaud in {2,4,5,8,10,16}, numAvg <= 512
+// (window history of ceil(numAvg/128) <= 4 blocks in registers)
+constexpr uint32_t kFastMaxNumAvg = 512;
 inline bool fast_kernel_has_S(uint32_t S)
 {
     return S == 2 || S == 4 || S == 5 || S == 8 || S == 10 || S == 16;
@@ -109,6 +112,8 @@ inline void ctl_linfit_reset(ChanCtl &c, uint32_t fit_cap, const uint64_t *numPt
 // One serviceFunction() call, control flow only.  Fills `plan` (device work) and the
 // result fields of `out`.  On a status other than PSK_SOFT_OK the caller discards `c`
 // (it plans on a copy), so a refused call leaves the channel untouched.
+inline uint64_t plan_lf_count0(const ChanCtl &c) { return c.lf_recompute_pending ? 0 : c.lf_count; }
+
 inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_packet_t &pkt,
                                  psk_soft_output_t &out, ChanPlan &plan)
 {
@@ -239,7 +244,8 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         c.count = (c.count + n_out) % kResyncCount;  // :581-583
         plan.ring_len1 = (uint32_t)c.ring_len;
         bool fast_ok = !lim.force_seq && fast_kernel_has_S((uint32_t)S) && c.lf_n <= lim.fast_fit_max &&
-                       n_out <= kResyncCount && A <= 0x7fffffffu;
+                       n_out <= kResyncCount && A <= kFastMaxNumAvg &&
+                       ((plan_lf_count0(c)) + n_out <= kResyncCount);
         plan.mode = (n_out == 0 || fast_ok) ? PLAN_FAST : PLAN_SEQ;
         if (lim.force_seq && n_out > 0)
             plan.mode = PLAN_SEQ;

@@ -188,234 +188,17 @@ PSK_DEV void fit_rebuild_sums(YAt y_at, uint32_t len, float xdelta, double &ySum
 // ---------------------------------------------------------------------------------
 // wave-scan kernel
 // ---------------------------------------------------------------------------------
-struct FastCarry {
-    double ySum, xySum;    // LinearFit sums after the last processed symbol
-    float est;             // phaseEstimate
-    float last_re, last_im;
-    float den, xavg;       // LinearFit::denominator / xAvg
-    float m, b;
-    uint32_t q;            // number of values ever written to the LDS y ring (history included)
-    unsigned umax, umin1;  // exactness guard: max energy bits, min (energy bits - 1)
-    bool refuse;
-    uint32_t stat_blocks, stat_extra;
-};
+}  // namespace psk
 
-template <int S>
-PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, FastCarry &cy)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t A = p.A, M = p.M, n = p.lf_n;
-    const uint64_t n_out = p.n_out;
-    const float xd = p.lf_xdelta;
+#include "psk_fast_loop.h"
 
-    // ---- W_k(-1) = sum over the first A-1 symbols (resyncEnergy, cpp/psk_soft.cpp:619-636) ----
-    double Wc[S];
-    {
-        double acc[S];
-#pragma unroll
-        for (int k = 0; k < S; k++) acc[k] = 0.0;
-        for (uint64_t tau = lane; tau + 1 < A; tau += kWave) {
-            float2 x[S];
-            load_symbol<S>(X, tau, true, x);
-#pragma unroll
-            for (int k = 0; k < S; k++) {
-                float e = norm_f(x[k].x, x[k].y);
-                unsigned eb = __float_as_uint(e);
-                cy.umax = eb > cy.umax ? eb : cy.umax;
-                cy.umin1 = (eb - 1u) < cy.umin1 ? (eb - 1u) : cy.umin1;
-                acc[k] += (double)e;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < S; k++) Wc[k] = wave_sum_f64(acc[k]);
-    }
-    float e_old_carry[S];
-#pragma unroll
-    for (int k = 0; k < S; k++) e_old_carry[k] = 0.0f;
+namespace psk {
 
-    // steady-state fit constants (all lanes of a block past the warm-up share them)
-    float den_s = cy.den, xavg_s = cy.xavg;
-    if (n > 1)
-        fit_denominator(xd, n, den_s, xavg_s);
-    const double rden_s = 1.0 / (double)den_s, rpts_s = 1.0 / (double)n;
-
-    const uint64_t n_blocks = (n_out + kWave - 1) / kWave;
-    for (uint64_t c = 0; c < n_blocks; c++) {
-        const uint64_t i = c * kWave + lane;  // output symbol of this lane
-        const bool valid = i < n_out;
-        const uint64_t rem = n_out - c * kWave;
-        const int nv = rem < (uint64_t)kWave ? (int)rem : kWave;  // valid lanes of this block
-
-        // ---- timing recovery ----
-        float2 xn[S], xo[S];
-        load_symbol<S>(X, i + A - 1, valid, xn);  // newest symbol of the window of output i
-        load_symbol<S>(X, i, valid, xo);          // oldest symbol = the one output i is picked from
-        double bestW = 0.0;
-        int bestK = 0;
-        float2 pick = xo[0];
-#pragma unroll
-        for (int k = 0; k < S; k++) {
-            float e_new = norm_f(xn[k].x, xn[k].y);
-            float e_out = norm_f(xo[k].x, xo[k].y);
-            unsigned eb = __float_as_uint(e_new);
-            cy.umax = eb > cy.umax ? eb : cy.umax;
-            cy.umin1 = (eb - 1u) < cy.umin1 ? (eb - 1u) : cy.umin1;
-            float e_old = wave_up1(e_out, e_old_carry[k]);  // energy of symbol i-1 at phase k
-            e_old_carry[k] = read_lane(e_out, 63);
-            double d = valid ? (double)e_new - (double)e_old : 0.0;
-            double W = Wc[k] + wave_scan_f64(d);
-            Wc[k] = read_lane(W, 63);
-            // std::max_element: first maximum, strict '<' (cpp/psk_soft.cpp:462)
-            if (k == 0) {
-                bestW = W;
-            } else if (bestW < W) {
-                bestW = W;
-                bestK = k;
-                pick = xo[k];
-            }
-        }
-
-        // ---- raw phase: arg(pow(sample, M)) (cpp/psk_soft.cpp:474) ----
-        cf32 s;
-        s.re = pick.x;
-        s.im = pick.y;
-        cf32 pw = cpow_uint<false>(s, M);
-        if (valid && !(is_fin(pw.re) && is_fin(pw.im)))
-            cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-        const double rawd = (double)lm_atan2f(pw.im, pw.re);
-
-        // ---- feedback unwrap + LinearFit::next, 64 symbols at a time ----
-        const uint32_t q0 = cy.q;
-        const uint32_t before = q0 + (uint32_t)lane;       // yvals.size() + pops so far, before this next()
-        const bool steady = before >= n;                   // cpp/psk_soft.cpp:54
-        const uint32_t size_b = steady ? n - 1 : before;   // yvals.size() at :78
-        const uint32_t pts = steady ? n : before + 1;      // yvals.size() at calculateFit
-        float den_l = den_s, xavg_l = xavg_s;
-        if (q0 < n && pts > 1 && pts < n)                  // warm-up: the window is still growing
-            fit_denominator(xd, pts, den_l, xavg_l);
-
-        // speculate numWraps by consecutive differences; lane 0 is exact (it sees the carried estimate)
-        int w;
-        {
-            double raw_prev = wave_up1(rawd, rawd);
-            int delta = (lane == 0) ? (int)unwrap_count(cy.est, rawd)
-                                    : (int)to_long_x86(__builtin_round((raw_prev - rawd) * kInvTwoPi));
-            delta = valid ? delta : 0;
-            w = wave_scan_i32(delta);
-        }
-        float y = 0.0f, est = 0.0f, m_l = 0.0f, b_l = 0.0f;
-        double ySum_l = 0.0, xySum_l = 0.0;
-        int pass = 0;
-        for (;;) {
-            double yd = rawd + (double)(long long)w * kTwoPi;  // cpp/psk_soft.cpp:478
-            y = (float)yd;                                      // next(float yval), :481
-            if (valid)
-                yring[(q0 + lane) & kYMask] = y;
-            wave_lds_fence();
-            float z = (valid && steady) ? yring[(before - n) & kYMask] : 0.0f;  // yvals.front(), :70
-            wave_lds_fence();
-            double y_d = valid ? (double)y : 0.0;
-            ySum_l = cy.ySum + wave_scan_f64(y_d - (double)z);
-            double ySum_prev = wave_up1(ySum_l, cy.ySum);
-            double ySumP = ySum_prev - (double)z;               // ySum after the pop, :70
-            float t = y * (float)size_b;                        // :78, size before the push
-            t = t * xd;
-            double cterm = (double)t - (steady ? (double)xd * ySumP : 0.0);  // :72 and :78
-            cterm = valid ? cterm : 0.0;
-            xySum_l = cy.xySum + wave_scan_f64(cterm);
-            if (q0 >= n) {  // steady state: both divisors are wave-uniform
-                est = fit_value_known(ySum_l, xySum_l, xd, n, den_s, xavg_s, rden_s, rpts_s, m_l, b_l);
-            } else if (pts > 1) {
-                est = fit_value(ySum_l, xySum_l, xd, pts, den_l, xavg_l, m_l, b_l);
-            } else {  // :164-171, a single point: b = yvals.back()
-                m_l = 0.0f;
-                b_l = y;
-                est = y;
-            }
-            float est_prev = wave_up1(est, cy.est);
-            int w2 = (int)unwrap_count(est_prev, rawd);  // cpp/psk_soft.cpp:477 with the true feedback
-            bool bad = valid && (w2 != w);
-            if (!__any(bad))
-                break;
-            w = w2;
-            if (++pass > kMaxUnwrapPasses) {
-                cy.refuse = true;
-                break;
-            }
-        }
-        cy.stat_blocks += 1;
-        cy.stat_extra += (uint32_t)pass;
-
-        // ---- de-rotation and hard decisions (cpp/psk_soft.cpp:484-566) ----
-        float phaseCorrection = 0.0f;
-        cf32 smp = s;
-        if (p.diff) {
-            cf32 last;
-            last.re = wave_up1(s.re, cy.last_re);
-            last.im = wave_up1(s.im, cy.last_im);
-            smp = cdiv(s, last);
-        } else {
-            phaseCorrection = -est / (float)M;
-        }
-        if (M == 4)
-            phaseCorrection = (float)((double)phaseCorrection + kPi4);
-        float sn, cs;
-        lm_sincosf(phaseCorrection, &sn, &cs);
-        cf32 ph;
-        ph.re = 1.0f * cs;
-        ph.im = 1.0f * sn;
-        cf32 corr = cmul<true>(smp, ph);
-
-        if (valid) {
-            if (p.soft)
-                reinterpret_cast<float2 *>(p.soft)[i] = make_float2(corr.re, corr.im);
-            if (p.phase)
-                p.phase[i] = est;
-            if (p.sidx)
-                p.sidx[i] = (int16_t)(unsigned short)bestK;
-            if (!p.bits) {
-            } else if (p.bpb == 1) {
-                p.bits[i] = (int16_t)(corr.re < 0);
-            } else if (p.bpb == 2) {  // quirk Q1: float -> bool is "!= 0"
-                int r = (corr.re != 0), im = (corr.im != 0);
-                short2 b2;
-                b2.x = (short)(r ^ im);
-                b2.y = (short)(!im);
-                reinterpret_cast<short2 *>(p.bits)[i] = b2;
-            } else if (p.bpb == 3) {
-                unsigned short sym = slice_8psk(corr.re, corr.im);
-                p.bits[3 * i + 0] = (int16_t)(sym & 1);
-                p.bits[3 * i + 1] = (int16_t)((sym >> 1) & 1);
-                p.bits[3 * i + 2] = (int16_t)((sym >> 2) & 1);
-            }
-        }
-
-        // ---- carries into the next block ----
-        cy.ySum = read_lane(ySum_l, nv - 1);
-        cy.xySum = read_lane(xySum_l, nv - 1);
-        cy.est = read_lane(est, nv - 1);
-        cy.m = read_lane(m_l, nv - 1);
-        cy.b = read_lane(b_l, nv - 1);
-        cy.last_re = read_lane(s.re, nv - 1);
-        cy.last_im = read_lane(s.im, nv - 1);
-        {
-            uint32_t pts_last = (q0 + nv - 1 >= n) ? n : q0 + nv;  // window size after the last next()
-            if (pts_last > 1 && pts_last < n) {
-                cy.den = read_lane(den_l, nv - 1);
-                cy.xavg = read_lane(xavg_l, nv - 1);
-            } else if (pts_last > 1) {
-                cy.den = den_s;
-                cy.xavg = xavg_s;
-            }
-        }
-        cy.q = q0 + (uint32_t)nv;
-    }
-}
-
-// SV = samplesPerBaud this instantiation handles; SV == 0 takes the channels of the batch that
-// emit nothing this call (warm-up, stalled window) whatever their samplesPerBaud.
-template <int SV>
-__global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+// SV = samplesPerBaud this instantiation handles, HV = ceil(numAvg / 128) (blocks of window
+// history kept in registers); SV == 0 takes the channels of the batch that emit nothing this
+// call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
+template <int SV, int HV>
+__global__ __launch_bounds__(64, (HV == 1 ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
 {
@@ -424,7 +207,8 @@ __global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict
     const ChanPlan &p = plans[blockIdx.x];
     if (p.mode != PLAN_FAST)
         return;
-    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV))
+    if (SV == 0 ? (p.n_out != 0)
+                : (p.n_out == 0 || p.S != (uint32_t)SV || (p.A + (uint32_t)kB - 1u) / (uint32_t)kB != (uint32_t)HV))
         return;
     const uint32_t ch = ch0 + blockIdx.x;
     ChanState *st = &states[ch];
@@ -453,6 +237,7 @@ __global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict
     cy.m = st->lf_m;
     cy.b = st->lf_b;
     cy.q = len0;
+    cy.last_k = st->last_k < p.S ? st->last_k : 0u;
     cy.umax = 0u;
     cy.umin1 = 0xFFFFFFFFu;
     cy.refuse = false;
@@ -471,7 +256,7 @@ __global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict
 
     // ---- the symbol loop ----
     if constexpr (SV != 0)
-        fast_main_loop<SV>(p, X, yring, cy);
+        fast_main_loop<SV, HV>(p, X, yring, cy);
 
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
     //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53 ----
@@ -484,7 +269,7 @@ __global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict
             int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
             emax = emax < 1 ? 1 : emax;
             emin = emin < 1 ? 1 : emin;
-            int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kWave));
+            int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
             if (24 + (emax - emin) + terms_log2 > 52)
                 cy.refuse = true;
         }
@@ -543,6 +328,7 @@ __global__ __launch_bounds__(64) void psk_fast_kernel(const ChanPlan *__restrict
             st->lf_m = cy.m;
             st->lf_b = cy.b;
             st->guard = 0u;
+            st->last_k = cy.last_k;
             st->stat_blocks = cy.stat_blocks;
             st->stat_extra = cy.stat_extra;
         }
@@ -824,25 +610,35 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
 // launchers (called from psk_capi.cpp through plain C++ declarations)
 // ---------------------------------------------------------------------------------
 namespace psk {
-// S = 0 launches the append-only variant; S in {2,4,5,8,10,16} the symbol loop for that samplesPerBaud.
-hipError_t launch_fast(int S, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
-                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream)
+// S = 0 launches the append-only variant; otherwise S in {2,4,5,8,10,16} and H = ceil(numAvg/128) in {1,2,4}
+// (H = 3 runs on the H = 4 instantiation's sibling below).
+hipError_t launch_fast(int S, int H, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
+                       float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream)
 {
     if (!nch)
         return hipSuccess;
-#define PSK_LAUNCH(SV)                                                                                             \
-    hipLaunchKernelGGL(psk_fast_kernel<SV>, dim3(nch), dim3(kWave), 0, stream, plans, ch0, states, rings, ring_cap, \
-                       yvs, fit_cap)
+#define PSK_LAUNCH(SV, HV)                                                                                          \
+    hipLaunchKernelGGL((psk_fast_kernel<SV, HV>), dim3(nch), dim3(kWave), 0, stream, plans, ch0, states, rings,      \
+                       ring_cap, yvs, fit_cap)
+#define PSK_LAUNCH_H(SV)                 \
+    switch (H) {                         \
+    case 1: PSK_LAUNCH(SV, 1); break;    \
+    case 2: PSK_LAUNCH(SV, 2); break;    \
+    case 3: PSK_LAUNCH(SV, 3); break;    \
+    case 4: PSK_LAUNCH(SV, 4); break;    \
+    default: return hipErrorInvalidValue; \
+    }
     switch (S) {
-    case 0: PSK_LAUNCH(0); break;
-    case 2: PSK_LAUNCH(2); break;
-    case 4: PSK_LAUNCH(4); break;
-    case 5: PSK_LAUNCH(5); break;
-    case 8: PSK_LAUNCH(8); break;
-    case 10: PSK_LAUNCH(10); break;
-    case 16: PSK_LAUNCH(16); break;
+    case 0: PSK_LAUNCH(0, 1); break;
+    case 2: PSK_LAUNCH_H(2); break;
+    case 4: PSK_LAUNCH_H(4); break;
+    case 5: PSK_LAUNCH_H(5); break;
+    case 8: PSK_LAUNCH_H(8); break;
+    case 10: PSK_LAUNCH_H(10); break;
+    case 16: PSK_LAUNCH_H(16); break;
     default: return hipErrorInvalidValue;
     }
+#undef PSK_LAUNCH_H
 #undef PSK_LAUNCH
     return hipGetLastError();
 }

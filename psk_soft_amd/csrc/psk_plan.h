@@ -69,7 +69,8 @@ struct ChanState {
     // statistics of the last call
     uint32_t stat_blocks;
     uint32_t stat_extra;
-    uint32_t pad[2];
+    uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
+    uint32_t pad;
 };
 
 }  // namespace psk
