@@ -139,6 +139,28 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
     return r;
 }
 
+// atan2f / sincosf for a whole wave: the straight-line form, and the general routine only if
+// some lane holds a special argument (wave-uniform branch, practically never taken)
+PSK_DEV float atan2f_wave(float y, float x)
+{
+    bool sp;
+    float r = lm_atan2f_ordinary(y, x, &sp);
+    if (__any(sp)) {
+        if (sp)
+            r = lm_atan2f(y, x);
+    }
+    return r;
+}
+PSK_DEV void sincosf_wave(float t, float *sn, float *cs)
+{
+    bool sp;
+    lm_sincosf_ordinary(t, sn, cs, &sp);
+    if (__any(sp)) {
+        if (sp)
+            lm_sincosf(t, sn, cs);
+    }
+}
+
 // (long) of a double as x86-64 cvttsd2si does it (cpp/psk_soft.cpp:477, 598)
 PSK_DEV long long to_long_x86(double v)
 {
@@ -219,7 +241,7 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 // 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
 PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
 {
-    float theta = lm_atan2f(c_im, c_re);
+    float theta = atan2f_wave(c_im, c_re);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)
         softsym = softsym + 8.0f;

@@ -19,8 +19,11 @@
 
 namespace psk {
 
-#ifndef PSK_PREFETCH_NEXT_BLOCK
-#define PSK_PREFETCH_NEXT_BLOCK 0  // 1: issue block c+1's loads before the phase part of block c (+32 VGPRs)
+#ifndef PSK_PREFETCH
+#define PSK_PREFETCH 0  // 1: issue block c+1's loads before the phase part of block c
+#endif
+#ifndef PSK_WAVES_H1
+#define PSK_WAVES_H1 4  // waves per SIMD the H = 1 instantiations are register-limited to
 #endif
 constexpr int kR = 2;             // symbols per lane per block
 constexpr int kB = kWave * kR;    // symbols per block
@@ -38,6 +41,16 @@ struct FastCarry {
     uint32_t stat_blocks, stat_extra;
 };
 
+// exactness guard bookkeeping: max of the energy bit patterns and min of (bits - 1); a zero
+// energy gives bits 0 / 0xFFFFFFFF and so constrains neither
+PSK_DEV void guard_track(FastCarry &cy, float e)
+{
+    const unsigned eb = __float_as_uint(e);
+    cy.umax = eb > cy.umax ? eb : cy.umax;
+    const unsigned em = eb - 1u;
+    cy.umin1 = em < cy.umin1 ? em : cy.umin1;
+}
+
 // what a block keeps of the symbols it loaded (positions s = 2*lane + r)
 template <int S>
 struct BlockKeep {
@@ -51,22 +64,46 @@ PSK_DEV float bperm(int src_lane, float v)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 PSK_DEV int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+PSK_DEV float bperm_addr(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+PSK_DEV int bperm_addr(int addr, int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
 
-// Value at stream position (this block's position s) - v, 1 <= v < kB, where positions >= 0 lie
-// in `newer` and negative ones in `older` (the block before it).  r-th result for this lane.
-template <class T>
-PSK_DEV T rot_fetch(int lane, int r, int v, const T (&newer)[kR], const T (&older)[kR])
+// Cross-lane fetch of "the value that sat D symbol positions earlier in the stream of loaded
+// symbols" (D = numAvg for the energies leaving the window, numAvg-1 for the picked-from symbol).
+// D = u*kB + v with 1 <= v <= kB (D = 0: u = v = 0): positions s >= v of this block find it in
+// block c-u ("newer"), the others in block c-u-1 ("older").  The per-lane parameters depend only
+// on numAvg, so they are computed once per call; the fetch itself is branch-free.
+struct RotParam {
+    int u;            // how many blocks back "newer" is (wave-uniform)
+    bool odd;         // v odd: the two slots of a lane swap roles
+    int src_addr[kR]; // byte address (lane*4) this lane pulls slot r from
+    bool offer_old[kR];  // what this lane offers for the puller of its slot r: older or newer block
+};
+PSK_DEV RotParam rot_param(int lane, unsigned D)
 {
-    const bool odd = (v & 1) != 0;
-    // what this lane OFFERS to the lane that will read slot (r ^ odd) of it; the array indices
-    // stay compile-time constants (a runtime index would push the arrays to scratch)
-    const int r_src = r ^ (int)odd;
-    const T nsel = odd ? newer[r ^ 1] : newer[r];
-    const T osel = odd ? older[r ^ 1] : older[r];
-    const int p_self = 2 * lane + r_src;
-    const T offered = (p_self >= kB - v) ? osel : nsel;
-    const int src_lane = (((2 * lane + r - v) & (kB - 1)) >> 1);
-    return bperm(src_lane, offered);
+    RotParam p;
+    const int u = D ? (int)((D - 1) / kB) : 0;
+    const int v = (int)D - u * kB;
+    p.u = u;
+    p.odd = (v & 1) != 0;
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        p.src_addr[r] = ((((2 * lane + r - v) & (kB - 1)) >> 1)) << 2;
+        const int r_src = r ^ (int)p.odd;  // the slot of the source lane that is read for result r
+        (void)r_src;
+        // this lane's slot q is pulled by result r = q ^ odd of some lane; that puller needs the
+        // older block iff its own position < v, i.e. iff this slot's position >= kB - v
+        p.offer_old[r] = (2 * lane + r) >= kB - v;
+    }
+    return p;
+}
+template <class T>
+PSK_DEV T rot_pull(const RotParam &p, int r, const T (&newer)[kR], const T (&older)[kR])
+{
+    // slot of the source lane read for result r (compile-time indices only: no scratch)
+    const T off0 = p.offer_old[0] ? older[0] : newer[0];
+    const T off1 = p.offer_old[1] ? older[1] : newer[1];
+    const T offered = (r == 0) ? (p.odd ? off1 : off0) : (p.odd ? off0 : off1);
+    return bperm_addr(p.src_addr[r], offered);
 }
 
 // x[k] for a per-lane k without a runtime-indexed array (which would live in scratch): a
@@ -109,14 +146,136 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
     }
 }
 
+// One block (128 symbols) of the feedback unwrap + LinearFit::next recurrence
+// (cpp/psk_soft.cpp:477-482, 48-87, 135-174).  WARM = the fit window is still growing somewhere in
+// the block (first phaseAvg symbols after a history clear): per-lane window sizes and denominators.
+// Returns the number of extra fixed-point passes; den_last / xavg_last = LinearFit::denominator /
+// xAvg after the block's last valid symbol.
+template <bool WARM>
+PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, double rden_s,
+                      double rpts_s, const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
+                      float *yring, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
+                      int lane_last, int r_last, float &den_last, float &xavg_last)
+{
+    uint32_t before[kR];
+    bool steady[kR];
+    float sizef[kR];   // (float)yvals.size() at cpp/psk_soft.cpp:78
+    uint32_t pts[kR];
+    float den_l[kR], xavg_l[kR];
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        before[r] = q0 + (uint32_t)(2 * lane + r);  // values pushed before this next()
+        if (WARM) {
+            steady[r] = before[r] >= n;              // cpp/psk_soft.cpp:54
+            sizef[r] = (float)(steady[r] ? n - 1 : before[r]);
+            pts[r] = steady[r] ? n : before[r] + 1;  // yvals.size() at calculateFit
+            den_l[r] = den_s;
+            xavg_l[r] = xavg_s;
+            if (pts[r] > 1 && pts[r] < n)            // the window is still growing
+                fit_denominator(xd, pts[r], den_l[r], xavg_l[r]);
+        } else {
+            steady[r] = true;
+            sizef[r] = (float)(n - 1);
+            pts[r] = n;
+            den_l[r] = den_s;
+            xavg_l[r] = xavg_s;
+        }
+    }
+    // speculate numWraps by consecutive differences; position 0 is exact (carried estimate)
+    int w[kR];
+    {
+        double raw_prev0 = wave_up1(rawd[1], rawd[1]);
+        int dl0 = (lane == 0) ? (int)unwrap_count(cy.est, rawd[0])
+                              : (int)to_long_x86(__builtin_round((raw_prev0 - rawd[0]) * kInvTwoPi));
+        int dl1 = (int)to_long_x86(__builtin_round((rawd[0] - rawd[1]) * kInvTwoPi));
+        int incl = wave_scan_i32(dl0 + dl1);
+        w[1] = incl;
+        w[0] = incl - dl1;
+    }
+    int pass = 0;
+    for (;;) {
+        double y_d[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            double yd = rawd[r] + (double)(long long)w[r] * kTwoPi;  // cpp/psk_soft.cpp:478
+            y[r] = (float)yd;                                         // next(float yval), :481
+            if (valid[r])
+                yring[(before[r]) & kYMask] = y[r];
+            y_d[r] = (double)y[r];  // (positions past the end only feed sums past the end)
+        }
+        wave_lds_fence();
+        float z[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++)
+            z[r] = steady[r] ? yring[(before[r] - n) & kYMask] : 0.0f;  // yvals.front(), :70
+        wave_lds_fence();
+        const double dy0 = y_d[0] - (double)z[0], dy1 = y_d[1] - (double)z[1];
+        double incl = wave_scan_f64(dy0 + dy1);
+        double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
+        double ySumP0 = base - (double)z[0];           // ySum after the pop, :70
+        ySum_l[0] = base + dy0;
+        double ySumP1 = ySum_l[0] - (double)z[1];
+        ySum_l[1] = ySum_l[0] + dy1;
+        float t0 = y[0] * sizef[0];                    // :78, size before the push
+        t0 = t0 * xd;
+        float t1 = y[1] * sizef[1];
+        t1 = t1 * xd;
+        double c0 = (double)t0 - (steady[0] ? (double)xd * ySumP0 : 0.0);  // :72 and :78
+        double c1 = (double)t1 - (steady[1] ? (double)xd * ySumP1 : 0.0);
+        double incl2 = wave_scan_f64(c0 + c1);
+        double base2 = cy.xySum + wave_up1(incl2, 0.0);
+        xySum_l[0] = base2 + c0;
+        xySum_l[1] = xySum_l[0] + c1;
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            float m_, b_;
+            if (!WARM) {  // steady state: both divisors are wave-uniform
+                est[r] = fit_value_known(ySum_l[r], xySum_l[r], xd, n, den_s, xavg_s, rden_s, rpts_s, m_, b_);
+            } else if (pts[r] > 1) {
+                est[r] = fit_value(ySum_l[r], xySum_l[r], xd, pts[r], den_l[r], xavg_l[r], m_, b_);
+            } else {  // :164-171, a single point: b = yvals.back()
+                est[r] = y[r];
+            }
+        }
+        float est_prev0 = wave_up1(est[1], cy.est);
+        int w2_0 = (int)unwrap_count(est_prev0, rawd[0]);  // cpp/psk_soft.cpp:477 with the true feedback
+        int w2_1 = (int)unwrap_count(est[0], rawd[1]);
+        bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
+        if (!__any(bad))
+            break;
+        w[0] = w2_0;
+        w[1] = w2_1;
+        if (++pass > 2 * kMaxUnwrapPasses)
+            break;
+    }
+    if (WARM) {
+        den_last = read_lane(r_last ? den_l[1] : den_l[0], lane_last);
+        xavg_last = read_lane(r_last ? xavg_l[1] : xavg_l[0], lane_last);
+    }
+    return pass;
+}
+
+// block j back in time: 0 = the block being processed, j >= 1 = hist[j-1]; u is wave-uniform
+template <int S, int H, class F>
+PSK_DEV float pick_block_e(int u, const BlockKeep<S> &cur, const BlockKeep<S> (&hist)[H], int older, F field)
+{
+    // value of `field` in block (u + older) back
+    float v = field(u + older == 0 ? cur : hist[0]);
+#pragma unroll
+    for (int j = 1; j <= H; j++)
+        if (u + older == j)
+            v = field(hist[j - 1 < H ? j - 1 : H - 1]);
+    return v;
+}
+
 template <int S, int H>
 PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, FastCarry &cy)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t A = p.A, M = p.M, n = p.lf_n;
-    const long long n_out = (long long)p.n_out;
+    const int n_out = (int)p.n_out;  // <= 2^20 on this path
     const float xd = p.lf_xdelta;
-    const long long tau_last = n_out + (long long)A - 2;  // newest symbol any emitted window uses
+    const long long tau_last = (long long)n_out + (long long)A - 2;  // newest symbol any emitted window uses
 
     // ---- prologue: the first A-1 symbols (the carried window) as "blocks" -H .. -1:
     //      W_k(-1) = their energy sums (= resyncEnergy, cpp/psk_soft.cpp:619-636) ----
@@ -136,11 +295,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
 #pragma unroll
                 for (int k = 0; k < S; k++) {
                     float e = norm_f(x[r][k].x, x[r][k].y);
-                    if (ok[r]) {
-                        unsigned eb = __float_as_uint(e);
-                        cy.umax = eb > cy.umax ? eb : cy.umax;
-                        cy.umin1 = (eb - 1u) < cy.umin1 ? (eb - 1u) : cy.umin1;
-                    }
+                    guard_track(cy, e);  // zero-filled (absent) symbols are neutral
                     hist[h].e[r][k] = e;
                     acc[k] += (double)e;
                 }
@@ -152,79 +307,99 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
         for (int k = 0; k < S; k++) Wc[k] = wave_sum_f64(acc[k]);
     }
 
-    // rotation distances: energies leave the window A symbols after they entered it; the
-    // picked-from symbol entered it A-1 symbols ago
-    const int uE = (int)(A / kB), vE = (int)(A % kB);
-    const int uP = (int)((A - 1) / kB), vP = (int)((A - 1) % kB);
+    // cross-lane fetch parameters: energies leave the window A symbols after they entered it;
+    // the picked-from symbol entered it A-1 symbols ago
+    const RotParam rotE = rot_param(lane, A);
+    const RotParam rotP = rot_param(lane, A - 1);
 
     // steady-state fit constants
     float den_s = cy.den, xavg_s = cy.xavg;
     if (n > 1)
         fit_denominator(xd, n, den_s, xavg_s);
     const double rden_s = 1.0 / (double)den_s, rpts_s = 1.0 / (double)n;
+    // -est/M (cpp/psk_soft.cpp:494): for a power-of-two M the division is an exact scaling
+    const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
+    const float inv_M = 1.0f / (float)(M ? M : 1);
 
-    const long long n_blocks = (n_out + kB - 1) / kB;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
     float2 xn[kR][S];
     bool okn[kR];
-#if PSK_PREFETCH_NEXT_BLOCK
+#if PSK_PREFETCH
     load_block<S>(X, 0, A, 0, tau_last, lane, xn, okn);
 #endif
 
-    for (long long c = 0; c < n_blocks; c++) {
-#if !PSK_PREFETCH_NEXT_BLOCK
-        load_block<S>(X, c, A, 0, tau_last, lane, xn, okn);
+    for (int c = 0; c < n_blocks; c++) {
+#if !PSK_PREFETCH
+        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn, okn);
 #endif
-        const long long i0 = c * kB + 2 * lane;  // first output symbol of this lane
+        const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
         valid[1] = i0 + 1 < n_out;
-        const long long rem = n_out - c * kB;
-        const int nvalid = rem < (long long)kB ? (int)rem : kB;  // valid positions of this block
+        const int rem = n_out - c * kB;
+        const int nvalid = rem < kB ? rem : kB;  // valid positions of this block
         const int lane_last = (nvalid - 1) >> 1, r_last = (nvalid - 1) & 1;
 
         // ================= timing recovery =================
+        // energies of the new symbols; of their samples keep the one at the predicted timing index
         BlockKeep<S> cur;
 #pragma unroll
-        for (int r = 0; r < kR; r++)
+        for (int r = 0; r < kR; r++) {
 #pragma unroll
             for (int k = 0; k < S; k++) {
                 float e = norm_f(xn[r][k].x, xn[r][k].y);
-                if (okn[r]) {
-                    unsigned eb = __float_as_uint(e);
-                    cy.umax = eb > cy.umax ? eb : cy.umax;
-                    cy.umin1 = (eb - 1u) < cy.umin1 ? (eb - 1u) : cy.umin1;
-                }
+                guard_track(cy, e);
                 cur.e[r][k] = e;
             }
+            cur.kp[r] = kpred[r];
+            cur.pk[r] = select_sample<S>(xn[r], kpred[r]);
+        }
+        // energy of symbol i-1 for every phase (it entered the window A symbols before symbol
+        // i+A-1 did): all cross-lane fetches issued back to back
+        float e_old[kR][S];
+#pragma unroll
+        for (int k = 0; k < S; k++) {
+            float nw[kR], od[kR];
+#pragma unroll
+            for (int rr = 0; rr < kR; rr++) {
+                nw[rr] = pick_block_e<S, H>(rotE.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                od[rr] = pick_block_e<S, H>(rotE.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+            }
+#pragma unroll
+            for (int r = 0; r < kR; r++) e_old[r][k] = rot_pull<float>(rotE, r, nw, od);
+        }
+        // the sample kept A-1 symbols ago for the symbol now being output, and the index it was kept at
+        float px[kR], py[kR];
+        int pkk[kR];
+        {
+            float nx[kR], ox[kR], ny[kR], oy[kR];
+            int nk[kR], ok2[kR];
+#pragma unroll
+            for (int rr = 0; rr < kR; rr++) {
+                nx[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
+                ox[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
+                ny[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
+                oy[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
+                nk[rr] = __float_as_int(pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return __int_as_float(b.kp[rr]); }));
+                ok2[rr] = __float_as_int(pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return __int_as_float(b.kp[rr]); }));
+            }
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                px[r] = rot_pull<float>(rotP, r, nx, ox);
+                py[r] = rot_pull<float>(rotP, r, ny, oy);
+                pkk[r] = rot_pull<int>(rotP, r, nk, ok2);
+            }
+        }
 
         double bestW[kR] = {0.0, 0.0};
         int bestK[kR] = {0, 0};
 #pragma unroll
         for (int k = 0; k < S; k++) {
-            // energy of symbol i-1 (it entered the window A symbols before symbol i+A-1 did)
-            float e_old[kR];
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                float nw[kR], od[kR];
-                // blocks (c - uE) and (c - uE - 1); block 0 back = cur, j back = hist[j-1]
-#pragma unroll
-                for (int rr = 0; rr < kR; rr++) {
-                    nw[rr] = cur.e[rr][k];
-                    od[rr] = hist[0].e[rr][k];
-                }
-#pragma unroll
-                for (int j = 1; j <= H; j++)
-                    if (uE == j) {
-#pragma unroll
-                        for (int rr = 0; rr < kR; rr++) {
-                            nw[rr] = hist[j - 1].e[rr][k];
-                            od[rr] = hist[j < H ? j : H - 1].e[rr][k];
-                        }
-                    }
-                e_old[r] = (vE == 0) ? nw[r] : rot_fetch<float>(lane, r, vE, nw, od);
-            }
-            double d0 = valid[0] ? (double)cur.e[0][k] - (double)e_old[0] : 0.0;
-            double d1 = valid[1] ? (double)cur.e[1][k] - (double)e_old[1] : 0.0;
+            // positions past the end of the call only pollute sums of later positions, which are
+            // past the end too: no masking needed
+            double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
+            double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
             double t1 = d0 + d1;                        // exact: float-valued addends (Q8)
             double incl = wave_scan_f64(t1);
             double W1 = Wc[k] + incl;                   // window sum of the lane's second symbol
@@ -246,65 +421,28 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             }
         }
 
-        // what this block keeps of its new symbols: the sample at the index just chosen
+        // the sample to output: kept at a predicted index -- verify, else re-read (rare, exact either way)
+        cf32 s[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
-            cur.kp[r] = bestK[r];
-            cur.pk[r] = select_sample<S>(xn[r], bestK[r]);
-        }
-
-        // the sample to output: kept (A-1 symbols ago) at a predicted index -- verify, else re-read
-        cf32 s[kR];
-        {
-            bool miss_any = false;
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                float nx[kR], ox[kR], ny[kR], oy[kR];
-                int nk[kR], ok2[kR];
-#pragma unroll
-                for (int rr = 0; rr < kR; rr++) {
-                    nx[rr] = cur.pk[rr].x; ny[rr] = cur.pk[rr].y; nk[rr] = cur.kp[rr];
-                    ox[rr] = hist[0].pk[rr].x; oy[rr] = hist[0].pk[rr].y; ok2[rr] = hist[0].kp[rr];
-                }
-#pragma unroll
-                for (int j = 1; j <= H; j++)
-                    if (uP == j) {
-#pragma unroll
-                        for (int rr = 0; rr < kR; rr++) {
-                            nx[rr] = hist[j - 1].pk[rr].x; ny[rr] = hist[j - 1].pk[rr].y; nk[rr] = hist[j - 1].kp[rr];
-                            const int jo = j < H ? j : H - 1;
-                            ox[rr] = hist[jo].pk[rr].x; oy[rr] = hist[jo].pk[rr].y; ok2[rr] = hist[jo].kp[rr];
-                        }
-                    }
-                float px, py;
-                int pkk;
-                if (vP == 0) {
-                    px = nx[r]; py = ny[r]; pkk = nk[r];
-                } else {
-                    px = rot_fetch<float>(lane, r, vP, nx, ox);
-                    py = rot_fetch<float>(lane, r, vP, ny, oy);
-                    pkk = rot_fetch<int>(lane, r, vP, nk, ok2);
-                }
-                const bool miss = valid[r] && (pkk != bestK[r]);
-                if (miss) {  // timing index moved since the prediction: re-read (rare)
-                    float2 g = x_at(X, (uint64_t)(i0 + r) * S + (uint64_t)bestK[r]);
-                    px = g.x;
-                    py = g.y;
-                }
-                miss_any |= miss;
-                s[r].re = px;
-                s[r].im = py;
+            const bool miss = valid[r] && (pkk[r] != bestK[r]);
+            if (miss) {
+                float2 g = x_at(X, (uint64_t)(i0 + r) * S + (uint64_t)bestK[r]);
+                px[r] = g.x;
+                py[r] = g.y;
             }
-            (void)miss_any;
+            s[r].re = px[r];
+            s[r].im = py[r];
+            kpred[r] = valid[r] ? bestK[r] : kpred[r];
         }
 
-        // history for the next block; prefetch its new symbols (their latency hides under the
-        // phase part below)
+        // history for the next block
 #pragma unroll
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;
-#if PSK_PREFETCH_NEXT_BLOCK
-        load_block<S>(X, c + 1, A, 0, tau_last, lane, xn, okn);
+#if PSK_PREFETCH
+        // prefetch the next block's symbols: their latency hides under the phase part below
+        load_block<S>(X, (long long)c + 1, A, 0, tau_last, lane, xn, okn);
 #endif
 
         // ================= raw phase: arg(pow(sample, M)) (cpp/psk_soft.cpp:474) =================
@@ -314,104 +452,24 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             cf32 pw = cpow_uint<false>(s[r], M);
             if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
                 cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-            rawd[r] = (double)lm_atan2f(pw.im, pw.re);
+            rawd[r] = (double)atan2f_wave(pw.im, pw.re);
         }
 
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
         const uint32_t q0 = cy.q;
-        uint32_t before[kR], size_b[kR], pts[kR];
-        bool steady[kR];
-        float den_l[kR], xavg_l[kR];
-#pragma unroll
-        for (int r = 0; r < kR; r++) {
-            before[r] = q0 + (uint32_t)(2 * lane + r);   // values pushed before this next()
-            steady[r] = before[r] >= n;                  // cpp/psk_soft.cpp:54
-            size_b[r] = steady[r] ? n - 1 : before[r];   // yvals.size() at :78
-            pts[r] = steady[r] ? n : before[r] + 1;      // yvals.size() at calculateFit
-            den_l[r] = den_s;
-            xavg_l[r] = xavg_s;
-            if (q0 < n && pts[r] > 1 && pts[r] < n)      // warm-up: the window is still growing
-                fit_denominator(xd, pts[r], den_l[r], xavg_l[r]);
+        float y[kR], est[kR];
+        double ySum_l[kR], xySum_l[kR];
+        float den_last = den_s, xavg_last = xavg_s;
+        int pass;
+        if (__builtin_expect(q0 >= n, 1)) {
+            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
+                                    xySum_l, lane_last, r_last, den_last, xavg_last);
+        } else {
+            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
+                                   xySum_l, lane_last, r_last, den_last, xavg_last);
         }
-
-        // speculate numWraps by consecutive differences; position 0 is exact (carried estimate)
-        int w[kR];
-        {
-            double raw_prev0 = wave_up1(rawd[1], rawd[1]);
-            int dl0 = (lane == 0) ? (int)unwrap_count(cy.est, rawd[0])
-                                  : (int)to_long_x86(__builtin_round((raw_prev0 - rawd[0]) * kInvTwoPi));
-            int dl1 = (int)to_long_x86(__builtin_round((rawd[0] - rawd[1]) * kInvTwoPi));
-            dl0 = valid[0] ? dl0 : 0;
-            dl1 = valid[1] ? dl1 : 0;
-            int incl = wave_scan_i32(dl0 + dl1);
-            w[1] = incl;
-            w[0] = incl - dl1;
-        }
-        float y[kR] = {0.0f, 0.0f}, est[kR] = {0.0f, 0.0f}, m_l[kR] = {0.0f, 0.0f}, b_l[kR] = {0.0f, 0.0f};
-        double ySum_l[kR] = {0.0, 0.0}, xySum_l[kR] = {0.0, 0.0};
-        int pass = 0;
-        for (;;) {
-            double y_d[kR];
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                double yd = rawd[r] + (double)(long long)w[r] * kTwoPi;  // cpp/psk_soft.cpp:478
-                y[r] = (float)yd;                                         // next(float yval), :481
-                if (valid[r])
-                    yring[(q0 + 2 * lane + r) & kYMask] = y[r];
-                y_d[r] = valid[r] ? (double)y[r] : 0.0;
-            }
-            wave_lds_fence();
-            float z[kR];
-#pragma unroll
-            for (int r = 0; r < kR; r++)
-                z[r] = (valid[r] && steady[r]) ? yring[(before[r] - n) & kYMask] : 0.0f;  // yvals.front(), :70
-            wave_lds_fence();
-            const double dy0 = y_d[0] - (double)z[0], dy1 = y_d[1] - (double)z[1];
-            {
-                double incl = wave_scan_f64(dy0 + dy1);
-                double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
-                double ySumP0 = base - (double)z[0];           // ySum after the pop, :70
-                ySum_l[0] = base + dy0;
-                double ySumP1 = ySum_l[0] - (double)z[1];
-                ySum_l[1] = ySum_l[0] + dy1;
-                float t0 = y[0] * (float)size_b[0];            // :78, size before the push
-                t0 = t0 * xd;
-                float t1 = y[1] * (float)size_b[1];
-                t1 = t1 * xd;
-                double c0 = (double)t0 - (steady[0] ? (double)xd * ySumP0 : 0.0);  // :72 and :78
-                double c1 = (double)t1 - (steady[1] ? (double)xd * ySumP1 : 0.0);
-                c0 = valid[0] ? c0 : 0.0;
-                c1 = valid[1] ? c1 : 0.0;
-                double incl2 = wave_scan_f64(c0 + c1);
-                double base2 = cy.xySum + wave_up1(incl2, 0.0);
-                xySum_l[0] = base2 + c0;
-                xySum_l[1] = xySum_l[0] + c1;
-            }
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                if (q0 >= n) {  // steady state: both divisors are wave-uniform
-                    est[r] = fit_value_known(ySum_l[r], xySum_l[r], xd, n, den_s, xavg_s, rden_s, rpts_s, m_l[r], b_l[r]);
-                } else if (pts[r] > 1) {
-                    est[r] = fit_value(ySum_l[r], xySum_l[r], xd, pts[r], den_l[r], xavg_l[r], m_l[r], b_l[r]);
-                } else {  // :164-171, a single point: b = yvals.back()
-                    m_l[r] = 0.0f;
-                    b_l[r] = y[r];
-                    est[r] = y[r];
-                }
-            }
-            float est_prev0 = wave_up1(est[1], cy.est);
-            int w2_0 = (int)unwrap_count(est_prev0, rawd[0]);  // cpp/psk_soft.cpp:477 with the true feedback
-            int w2_1 = (int)unwrap_count(est[0], rawd[1]);
-            bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
-            if (!__any(bad))
-                break;
-            w[0] = w2_0;
-            w[1] = w2_1;
-            if (++pass > 2 * kMaxUnwrapPasses) {
-                cy.refuse = true;
-                break;
-            }
-        }
+        if (pass > 2 * kMaxUnwrapPasses)
+            cy.refuse = true;
         cy.stat_blocks += 1;
         cy.stat_extra += (uint32_t)pass;
 
@@ -431,12 +489,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
                 }
                 smp = cdiv(s[r], last);
             } else {
-                phaseCorrection = -est[r] / (float)M;
+                phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
             }
             if (M == 4)
                 phaseCorrection = (float)((double)phaseCorrection + kPi4);
             float sn, cs;
-            lm_sincosf(phaseCorrection, &sn, &cs);
+            sincosf_wave(phaseCorrection, &sn, &cs);
             cf32 ph;
             ph.re = 1.0f * cs;
             ph.im = 1.0f * sn;
@@ -451,7 +509,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             typedef short s4u __attribute__((ext_vector_type(4), aligned(4)));
             if (p.soft) {
                 f4u v = {corr[0].re, corr[0].im, corr[1].re, corr[1].im};
-                *reinterpret_cast<f4u *>(p.soft + 2 * i0) = v;
+                *reinterpret_cast<f4u *>(p.soft + 2 * (size_t)i0) = v;
             }
             if (p.phase) {
                 f2u v = {est[0], est[1]};
@@ -506,28 +564,19 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             const double ys = r_last ? ySum_l[1] : ySum_l[0];
             const double xys = r_last ? xySum_l[1] : xySum_l[0];
             const float e_ = r_last ? est[1] : est[0];
-            const float mm = r_last ? m_l[1] : m_l[0];
-            const float bb = r_last ? b_l[1] : b_l[0];
             const float sre = r_last ? s[1].re : s[0].re;
             const float sim = r_last ? s[1].im : s[0].im;
             const int kk = r_last ? bestK[1] : bestK[0];
-            const float dl = r_last ? den_l[1] : den_l[0];
-            const float xl = r_last ? xavg_l[1] : xavg_l[0];
             cy.ySum = read_lane(ys, lane_last);
             cy.xySum = read_lane(xys, lane_last);
             cy.est = read_lane(e_, lane_last);
-            cy.m = read_lane(mm, lane_last);
-            cy.b = read_lane(bb, lane_last);
             cy.last_re = read_lane(sre, lane_last);
             cy.last_im = read_lane(sim, lane_last);
             cy.last_k = (uint32_t)__builtin_amdgcn_readlane(kk, lane_last);
             const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
-            if (pts_last > 1 && pts_last < n) {
-                cy.den = read_lane(dl, lane_last);
-                cy.xavg = read_lane(xl, lane_last);
-            } else if (pts_last > 1) {
-                cy.den = den_s;
-                cy.xavg = xavg_s;
+            if (pts_last > 1) {  // calculateDenominator ran for the window size reached (cpp/psk_soft.cpp:81-83)
+                cy.den = den_last;
+                cy.xavg = xavg_last;
             }
         }
         cy.q = q0 + (uint32_t)nvalid;

@@ -53,24 +53,37 @@ PSK_DEV double dpp_zero_f64(double v)
     hi = dpp_zero<CTRL, ROW_MASK>(hi);
     return __hiloint2double(hi, lo);
 }
+// row_shr:N with bound_ctrl:0 -- lanes whose source falls outside their row of 16 read 0, so no
+// "old" value has to be materialised (saves two v_mov per 64-bit step)
+template <int CTRL>
+PSK_DEV int dpp_shr0(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+PSK_DEV double dpp_shr0_f64(double v)
+{
+    int lo = dpp_shr0<CTRL>(__double2loint(v)), hi = dpp_shr0<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 // inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 inside each row of 16, then
 // row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
 PSK_DEV double wave_scan_f64(double v)
 {
-    v += dpp_zero_f64<0x111, 0xF>(v);
-    v += dpp_zero_f64<0x112, 0xF>(v);
-    v += dpp_zero_f64<0x114, 0xF>(v);
-    v += dpp_zero_f64<0x118, 0xF>(v);
+    v += dpp_shr0_f64<0x111>(v);
+    v += dpp_shr0_f64<0x112>(v);
+    v += dpp_shr0_f64<0x114>(v);
+    v += dpp_shr0_f64<0x118>(v);
     v += dpp_zero_f64<0x142, 0xA>(v);
     v += dpp_zero_f64<0x143, 0xC>(v);
     return v;
 }
 PSK_DEV int wave_scan_i32(int v)
 {
-    v += dpp_zero<0x111, 0xF>(v);
-    v += dpp_zero<0x112, 0xF>(v);
-    v += dpp_zero<0x114, 0xF>(v);
-    v += dpp_zero<0x118, 0xF>(v);
+    v += dpp_shr0<0x111>(v);
+    v += dpp_shr0<0x112>(v);
+    v += dpp_shr0<0x114>(v);
+    v += dpp_shr0<0x118>(v);
     v += dpp_zero<0x142, 0xA>(v);
     v += dpp_zero<0x143, 0xC>(v);
     return v;
@@ -198,7 +211,7 @@ namespace psk {
 // history kept in registers); SV == 0 takes the channels of the batch that emit nothing this
 // call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
 template <int SV, int HV>
-__global__ __launch_bounds__(64, (HV == 1 ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+__global__ __launch_bounds__(64, (HV == 1 ? PSK_WAVES_H1 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
 {
@@ -234,8 +247,6 @@ __global__ __launch_bounds__(64, (HV == 1 ? 4 : 1)) void psk_fast_kernel(const C
     cy.last_im = st->last_im;
     cy.den = st->lf_den;
     cy.xavg = st->lf_xavg;
-    cy.m = st->lf_m;
-    cy.b = st->lf_b;
     cy.q = len0;
     cy.last_k = st->last_k < p.S ? st->last_k : 0u;
     cy.umax = 0u;
@@ -325,8 +336,6 @@ __global__ __launch_bounds__(64, (HV == 1 ? 4 : 1)) void psk_fast_kernel(const C
             st->phaseEstimate = pe;
             st->lf_den = cy.den;
             st->lf_xavg = cy.xavg;
-            st->lf_m = cy.m;
-            st->lf_b = cy.b;
             st->guard = 0u;
             st->last_k = cy.last_k;
             st->stat_blocks = cy.stat_blocks;
@@ -628,6 +637,11 @@ hipError_t launch_fast(int S, int H, const ChanPlan *plans, uint32_t ch0, uint32
     case 4: PSK_LAUNCH(SV, 4); break;    \
     default: return hipErrorInvalidValue; \
     }
+#ifdef PSK_ONLY_S8H1
+    if (S == 8 && H == 1) { PSK_LAUNCH(8, 1); return hipGetLastError(); }
+    if (S == 0) { PSK_LAUNCH(0, 1); return hipGetLastError(); }
+    return hipErrorInvalidValue;
+#else
     switch (S) {
     case 0: PSK_LAUNCH(0, 1); break;
     case 2: PSK_LAUNCH_H(2); break;
@@ -638,9 +652,10 @@ hipError_t launch_fast(int S, int H, const ChanPlan *plans, uint32_t ch0, uint32
     case 16: PSK_LAUNCH_H(16); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+#endif
 #undef PSK_LAUNCH_H
 #undef PSK_LAUNCH
-    return hipGetLastError();
 }
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream)

@@ -242,6 +242,87 @@ PSK_HD void lm_sincosf(float y, float *sp, float *cp)
 }
 
 // ---------------------------------------------------------------------------------
+// Straight-line forms for SIMD execution.  They return the same bits as lm_atan2f /
+// lm_sincosf for every "ordinary" argument and set *special for the rest (NaN, inf, zeros,
+// x == 1, extreme ratios, |theta| >= 120): the caller then takes the general routine above.
+// tests/support/libm_pin.cpp checks fast == general wherever *special is false.
+// ---------------------------------------------------------------------------------
+PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
+{
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const uint32_t ux = lm_asuint(x), uy = lm_asuint(y);
+    const uint32_t ix = ux & 0x7fffffffu, iy = uy & 0x7fffffffu;
+    const float a = __builtin_fabsf(y / x);  // atanf argument, >= 0
+    const uint32_t ia = lm_asuint(a);
+    // ordinary: finite non-zero x and y, x != 1.0, 2^-29 <= |y/x| < 2^25 (which also keeps the
+    // exponent difference k of e_atan2f.c inside (-60, 60))
+    *special = (ix - 1u >= 0x7f7fffffu) || (iy - 1u >= 0x7f7fffffu) || (ux == 0x3f800000u) || (ia < 0x31000000u) ||
+               (ia >= 0x4c000000u);
+    // atanf(a), a > 0: range selection without branches
+    const bool r0 = ia < 0x3ee00000u;   // a < 7/16
+    const bool r1 = ia < 0x3f300000u;   // a < 11/16
+    const bool r2 = ia < 0x3f980000u;   // a < 19/16
+    const bool r3 = ia < 0x401c0000u;   // a < 39/16
+    const float num = r0 ? a : r1 ? (2.0f * a - 1.0f) : r2 ? (a - 1.0f) : r3 ? (a - 1.5f) : -1.0f;
+    const float den = r0 ? 1.0f : r1 ? (2.0f + a) : r2 ? (a + 1.0f) : r3 ? (1.0f + 1.5f * a) : a;
+    const float hi = r1 ? hi0 : r2 ? hi1 : r3 ? hi2 : hi3;
+    const float lo = r1 ? lo0 : r2 ? lo1 : r3 ? lo2 : lo3;
+    const float t = r0 ? a : num / den;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float p = t * (s1 + s2);
+    const float zat = r0 ? (t - p) : (hi - ((p - lo) - t));  // atanf(|y/x|)
+    // quadrant, e_atan2f.c switch (m)
+    const bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
+    const float q2 = pi - (zat - pi_lo);
+    const float q3 = (zat - pi_lo) - pi;
+    return xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+}
+
+// sinf / cosf for |y| < 120 as one straight line: reduce_fast with n = 0 is the identity for
+// |y| < pi/4, so the two ranges of s_sinf.c share the code; tiny |y| is patched at the end
+PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special)
+{
+    const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const uint32_t top = lm_abstop12(y);
+    *special = top >= lm_abstop12(120.0f);
+    const double x = (double)y;
+    const double r = x * HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double xr = __builtin_fma(-(double)n, HPI, x);
+    const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;  // sign[n & 3] = {1,-1,-1,1}
+    const double sg = (n & 2) ? -1.0 : 1.0;         // second table entry: cosine coefficients negated
+    const double xs = xr * sgn, x2 = xr * xr;
+    // sine polynomial
+    const double x3 = xs * x2;
+    const double s1 = __builtin_fma(x2, S3, S2);
+    const double x7 = x3 * x2;
+    const double s = __builtin_fma(x3, S1, xs);
+    const float ps = (float)__builtin_fma(x7, s1, s);
+    // cosine polynomial
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, sg * C4, sg * C3);
+    const double c1 = __builtin_fma(x2, sg * C1, sg * C0);
+    const double x6 = x4 * x2;
+    const double c = __builtin_fma(x4, sg * C2, c1);
+    const float pc = (float)__builtin_fma(x6, c2, c);
+    const bool odd = (n & 1) != 0;
+    const bool tiny = top < lm_abstop12(0x1p-12f);
+    *sp = tiny ? y : (odd ? pc : ps);
+    *cp = tiny ? 1.0f : (odd ? ps : pc);
+}
+
+// ---------------------------------------------------------------------------------
 // a / b for a divisor whose correctly rounded reciprocal rb = 1.0 / b is known
 // (Markstein: q = RN(a*rb), r = a - q*b exactly by fma, RN(q + r*rb) is the correctly
 // rounded quotient; the excluded case, a divisor significand of all ones, cannot occur for

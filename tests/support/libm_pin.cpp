@@ -29,7 +29,7 @@ static bool same(float a, float b) { return psk::lm_asuint(a) == psk::lm_asuint(
 int main(int argc, char **argv)
 {
     long n_each = argc > 1 ? atol(argv[1]) : 20000000;
-    long bad_s = 0, bad_c = 0, bad_a2 = 0, bad_a = 0, bad_d = 0;
+    long bad_s = 0, bad_c = 0, bad_a2 = 0, bad_a = 0, bad_d = 0, bad_fs = 0, bad_fa = 0, n_sp_s = 0, n_sp_a = 0;
     for (long i = 0; i < n_each; i++) {
         float x;
         switch (i % 6) {
@@ -44,6 +44,11 @@ int main(int argc, char **argv)
         psk::lm_sincosf(x, &s, &c);
         if (!same(s, sinf(x))) bad_s++;
         if (!same(c, cosf(x))) bad_c++;
+        bool sp;
+        float fs, fc;
+        psk::lm_sincosf_ordinary(x, &fs, &fc, &sp);
+        if (sp) n_sp_s++;
+        else if (!same(fs, s) || !same(fc, c)) bad_fs++;
     }
     for (long i = 0; i < n_each; i++) {
         float y, x;
@@ -57,6 +62,10 @@ int main(int argc, char **argv)
         }
         if (!same(psk::lm_atan2f(y, x), atan2f(y, x))) bad_a2++;
         if (!same(psk::lm_atanf(y), atanf(y))) bad_a++;
+        bool sp;
+        float fa = psk::lm_atan2f_ordinary(y, x, &sp);
+        if (sp) n_sp_a++;
+        else if (!same(fa, atan2f(y, x))) bad_fa++;
     }
     for (long i = 0; i < n_each; i++) {
         double b;
@@ -69,5 +78,6 @@ int main(int argc, char **argv)
         if (psk::lm_div_known(a, b, 1.0 / b) != a / b) bad_d++;
     }
     printf("n=%ld sinf_bad=%ld cosf_bad=%ld atan2f_bad=%ld atanf_bad=%ld div_bad=%ld\n", n_each, bad_s, bad_c, bad_a2, bad_a, bad_d);
-    return (bad_s || bad_c || bad_a2 || bad_a || bad_d) ? 1 : 0;
+    printf("ordinary forms: sincos_bad=%ld (special %ld) atan2_bad=%ld (special %ld)\n", bad_fs, n_sp_s, bad_fa, n_sp_a);
+    return (bad_s || bad_c || bad_a2 || bad_a || bad_d || bad_fs || bad_fa) ? 1 : 0;
 }
