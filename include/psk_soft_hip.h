@@ -108,11 +108,14 @@ typedef struct psk_soft_handle psk_soft_handle_t;
 
 /* Runtime statistics of the last psk_soft_process_* call (read after psk_soft_synchronize). */
 typedef struct psk_soft_stats {
-    uint64_t channels_fast;       /* channels handled by the wave-scan kernel                      */
+    uint64_t channels_fast;       /* channels handled by a wave-scan kernel                        */
+    uint64_t channels_exact_timing; /* of those: calls whose timing screening refused (near-ties) and
+                                       that the exact-timing wave-scan kernel redid                */
     uint64_t channels_sequential; /* channels handled by the reference-order kernel (planned)      */
     uint64_t channels_guard;      /* of those: sent there at run time by the exactness guard       */
-    uint64_t unwrap_extra_passes; /* extra unwrap fixed-point passes summed over all 64-symbol blocks */
-    uint64_t unwrap_blocks;       /* 64-symbol blocks processed by the wave-scan kernel            */
+    uint64_t unwrap_extra_passes; /* extra unwrap fixed-point passes summed over all 128-symbol blocks */
+    uint64_t unwrap_blocks;       /* 128-symbol blocks processed by the wave-scan kernel           */
+    uint64_t timing_exact_blocks; /* of those: blocks whose timing argmax needed the exact double pass */
 } psk_soft_stats_t;
 
 uint32_t psk_soft_abi_version(void);

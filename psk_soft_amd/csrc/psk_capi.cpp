@@ -19,7 +19,7 @@
 #include "psk_soft_hip.h"
 
 namespace psk {
-hipError_t launch_fast(int S, int H, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
+hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
@@ -277,7 +277,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (p.mode == psk::PLAN_FAST) {
             if (p.n_out) {
                 any_emit = true;
-                need_SH[p.S][(p.A + 127u) / 128u] = true;
+                need_SH[p.S][p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4] = true;
             } else {
                 any_quiet = true;
             }
@@ -298,13 +298,16 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
                            stream));
     if (any_quiet)
-        PSK_HIP(psk::launch_fast(0, 1, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+        PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                  h->lim.fit_cap, stream));
-    for (int S : kFastS)
-        for (int H = 1; H <= 4; H++)
-            if (need_SH[S][H])
-                PSK_HIP(psk::launch_fast(S, H, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap,
-                                         h->d_yv, h->lim.fit_cap, stream));
+    // screened timing first; the exact-timing instantiation picks up the calls it refused, the
+    // reference-order kernel (below) the calls both refused
+    for (int exact = 0; exact <= 1; exact++)
+        for (int S : kFastS)
+            for (int H = 1; H <= 4; H++)
+                if (need_SH[S][H])
+                    PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
+                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, stream));
     if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
         PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                 h->lim.fit_cap, stream));
@@ -423,8 +426,11 @@ psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats
                 stats->channels_guard++;
             } else {
                 stats->channels_fast++;
+                if (s[c].guard == 3u)
+                    stats->channels_exact_timing++;
                 stats->unwrap_blocks += s[c].stat_blocks;
                 stats->unwrap_extra_passes += s[c].stat_extra;
+                stats->timing_exact_blocks += s[c].stat_exact;
             }
             break;
         case psk::PLAN_SEQ:

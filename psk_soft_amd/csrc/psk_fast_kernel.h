@@ -1,0 +1,176 @@
+// psk_fast_kernel.h -- the wave-scan kernel: per-call prologue (LinearFit history, reset sums),
+// the symbol loop (psk_fast_loop.h), exactness guard, end-of-call wrap, state commit.
+#ifndef PSK_FAST_KERNEL_H
+#define PSK_FAST_KERNEL_H
+
+#include "psk_fast_loop.h"
+
+namespace psk {
+
+// number of 128-symbol blocks of window history an instantiation keeps in registers for numAvg = A
+PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 4; }
+
+// SV = samplesPerBaud this instantiation handles, HV = blocks of window history kept in
+// registers (numAvg <= 128 HV), EXACT = timing by the exact double pass (else the float
+// screening pass, see psk_fast_loop.h).  SV == 0 takes the channels of the batch that emit
+// nothing this call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
+// Register budget: the numAvg <= 128, samplesPerBaud <= 8 instantiations are held to 128 VGPRs
+// (4 waves per SIMD = 16 single-wave workgroups per CU, so a 4096-channel batch is resident at
+// once), samplesPerBaud = 10 to 168 (3 waves per SIMD); the others keep what they need.
+// Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
+// (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
+// runs on 1 and leaves 2.
+template <int SV, int HV, bool EXACT>
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 10) ? 3 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+                                                      ChanState *__restrict__ states, float2 *__restrict__ rings,
+                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
+{
+    __shared__ float yring[kYRing];
+    __shared__ float park[(SV != 0 && HV == 1) ? park_floats(SV == 0 ? 2 : SV) : 1];
+    const int lane = threadIdx.x & 63;
+    const ChanPlan &p = plans[blockIdx.x];
+    if (p.mode != PLAN_FAST)
+        return;
+    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV))
+        return;
+    if (EXACT && states[ch0 + blockIdx.x].guard != 1u)
+        return;  // the screened kernel finished this channel's call
+    const uint32_t ch = ch0 + blockIdx.x;
+    ChanState *st = &states[ch];
+    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
+    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
+    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
+    float *yv = yvs + (size_t)ch * fit_cap;
+
+    XView X;
+    X.ring = ring_src;
+    X.in = reinterpret_cast<const float2 *>(p.in);
+    X.L0 = p.ring_len0;
+
+    // ---- prologue: LinearFit history into the LDS ring; LinearFit::reset() sums if it ran ----
+    const uint32_t len0 = p.lf_len0, n = p.lf_n;
+    for (uint32_t j = lane; j < len0; j += kWave) yring[j & kYMask] = yv[(p.lf_head + j) % fit_cap];
+    wave_lds_fence();
+    FastCarry cy;
+    cy.ySum = st->lf_ySum;
+    cy.xySum = st->lf_xySum;
+    cy.est = st->phaseEstimate;
+    cy.last_re = st->last_re;
+    cy.last_im = st->last_im;
+    cy.den = st->lf_den;
+    cy.xavg = st->lf_xavg;
+    cy.q = len0;
+    cy.last_k = st->last_k < p.S ? st->last_k : 0u;
+    cy.umax = 0u;
+    cy.umin1 = 0xFFFFFFFFu;
+    cy.refuse = false;
+    cy.stat_blocks = 0;
+    cy.stat_extra = 0;
+    cy.stat_exact_blocks = 0;
+    if (p.lf_flags & LF_RECOMPUTE) {
+        fit_rebuild_sums([&](uint32_t j) { return yring[j & kYMask]; }, len0, p.lf_xdelta, cy.ySum, cy.xySum);
+        fit_denominator(p.lf_xdelta, len0, cy.den, cy.xavg);
+        if (len0 > 1) {
+            (void)fit_value(cy.ySum, cy.xySum, p.lf_xdelta, len0, cy.den, cy.xavg, cy.m, cy.b);
+        } else {
+            cy.m = 0.0f;
+            cy.b = len0 ? yring[(len0 - 1) & kYMask] : 0.0f;
+        }
+    }
+
+    // ---- the symbol loop ----
+    if constexpr (SV != 0)
+        fast_main_loop<SV, HV, EXACT>(p, X, yring, park, cy);
+
+    // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
+    //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53 ----
+    {
+        unsigned umax = wave_max_u32(cy.umax);
+        unsigned umin1 = wave_min_u32(cy.umin1);
+        if (umax >= 0x7F800000u)
+            cy.refuse = true;  // inf / NaN energy
+        if (umin1 != 0xFFFFFFFFu) {
+            int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
+            emax = emax < 1 ? 1 : emax;
+            emin = emin < 1 ? 1 : emin;
+            int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
+            if (24 + (emax - emin) + terms_log2 > 52)
+                cy.refuse = true;
+        }
+        cy.refuse = __any(cy.refuse);
+    }
+    if (cy.refuse) {
+        if (lane == 0)
+            st->guard = 1u;  // nothing committed: psk_seq_kernel redoes this call from the old state
+        return;
+    }
+
+    // ---- end-of-call wrap (cpp/psk_soft.cpp:592-603) ----
+    const uint32_t grown = len0 + (uint32_t)p.n_out;  // n_out <= 2^20 on this path
+    const uint32_t len1 = grown < n ? grown : n;
+    const uint32_t first = cy.q - len1;  // ring position of yvals.front()
+    float pe = cy.est;
+    const float wrapValue = (float)(kTwoPi * (double)p.M);
+    uint32_t count1 = 0;
+    if (wrap_test(pe, wrapValue)) {
+        float qv = pe / wrapValue;
+        long long numWraps = to_long_x86(__builtin_round((double)qv));
+        float cst = (float)numWraps * wrapValue;
+        for (uint32_t j = lane; j < len1; j += kWave) {  // LinearFit::subtractConst :126-133
+            float v = yring[(first + j) & kYMask];
+            yring[(first + j) & kYMask] = v - cst;
+        }
+        wave_lds_fence();
+        fit_rebuild_sums([&](uint32_t j) { return yring[(first + j) & kYMask]; }, len1, p.lf_xdelta, cy.ySum, cy.xySum);
+        fit_denominator(p.lf_xdelta, len1, cy.den, cy.xavg);
+        if (len1 > 1) {
+            pe = fit_value(cy.ySum, cy.xySum, p.lf_xdelta, len1, cy.den, cy.xavg, cy.m, cy.b);
+        } else {
+            cy.m = 0.0f;
+            cy.b = len1 ? yring[(first + len1 - 1) & kYMask] : 0.0f;
+            pe = cy.b;
+        }
+        count1 = 1;  // informational only: the host mirrors LinearFit::count
+    }
+    (void)count1;
+
+    // ---- commit the channel state ----
+    {
+        const uint32_t dropped = grown - len1;
+        const uint32_t head1 = (uint32_t)(((uint64_t)p.lf_head + dropped) % fit_cap);
+        for (uint32_t j = lane; j < len1; j += kWave) yv[(head1 + j) % fit_cap] = yring[(first + j) & kYMask];
+        const uint64_t drop = p.n_out * (uint64_t)p.S;  // samples popped by the emissions (:579-580)
+        for (uint32_t j = lane; j < p.ring_len1; j += kWave) ring_dst[j] = x_at(X, drop + j);
+        if (lane == 0) {
+            st->lf_ySum = cy.ySum;
+            st->lf_xySum = cy.xySum;
+            st->last_re = cy.last_re;
+            st->last_im = cy.last_im;
+            st->phaseEstimate = pe;
+            st->lf_den = cy.den;
+            st->lf_xavg = cy.xavg;
+            st->guard = EXACT ? 3u : 0u;
+            st->last_k = cy.last_k;
+            st->stat_blocks = cy.stat_blocks;
+            st->stat_extra = cy.stat_extra;
+            st->stat_exact = cy.stat_exact_blocks;
+        }
+    }
+}
+
+#define PSK_FAST_ARGS                                                                                          \
+    const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings, uint32_t ring_cap,    \
+        float *yvs, uint32_t fit_cap, hipStream_t stream
+
+template <int SV, int HV, bool EXACT>
+hipError_t launch_fast_inst(PSK_FAST_ARGS)
+{
+    if (!nch)
+        return hipSuccess;
+    hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), 0, stream, plans, ch0, states, rings,
+                       ring_cap, yvs, fit_cap);
+    return hipGetLastError();
+}
+
+}  // namespace psk
+#endif

@@ -1,4 +1,4 @@
-// psk_fast_loop.h -- the symbol loop of the wave-scan kernel (included by psk_kernels.hip).
+// psk_fast_loop.h -- the symbol loop of the wave-scan kernels.
 //
 // One wave walks one channel in blocks of B = 128 output symbols; lane l owns the two
 // consecutive symbols at block positions s = 2l and 2l+1 ("R = 2": every cross-lane scan,
@@ -9,36 +9,46 @@
 // symbol of a window (A-1 symbols before it is output).  What later steps need from it is kept
 // in registers for H = ceil(A/128) blocks and fetched across lanes with ds_bpermute:
 //   * its S energies  -- subtracted from the window sums A symbols later
-//                        (symbolEnergy[k] -= energy[k], cpp/psk_soft.cpp:572-577);
-//   * ONE of its samples, the one at the timing index the lane predicts (the index it has
-//     just chosen for its own output symbol).  When the symbol is output and the true
-//     argmax equals the prediction -- timing is stationary, so practically always -- the
-//     sample is already there; otherwise the lane re-reads it from memory (exact either way).
+//                        (symbolEnergy[k] -= energy[k], reference cpp/psk_soft.cpp:572-577);
+//   * ONE of its samples, the one at the timing index the lane chose one block earlier.  When the
+//     symbol is output and the true argmax equals that prediction -- timing is stationary, so
+//     practically always -- the sample is already there; otherwise the lane re-reads it from
+//     memory (exact either way).
+//
+// Timing argmax (reference cpp/psk_soft.cpp:445-466), two instantiations of the same loop:
+//   EXACT = false  "screened": the window sums are scanned in FLOAT (one fused DPP add per step,
+//                  no double arithmetic) together with a running bound of their rounding error;
+//                  the argmax is accepted only where the best sum beats the runner-up by more
+//                  than twice that bound, i.e. where the exact argmax provably equals it.  If any
+//                  symbol of the call fails the test the wave refuses the call (nothing
+//                  committed) and the EXACT = true kernel, launched right behind it, redoes it.
+//   EXACT = true   the sums are float-valued addends accumulated in double: exact, hence equal
+//                  to the reference's whatever the summation order (quirk Q8), under the
+//                  exponent-spread guard; near-ties resolve by std::max_element's first-maximum
+//                  rule exactly as the reference's do.
 #ifndef PSK_FAST_LOOP_H
 #define PSK_FAST_LOOP_H
 
+#include "psk_wave.h"
+
 namespace psk {
 
-#ifndef PSK_PREFETCH
-#define PSK_PREFETCH 0  // 1: issue block c+1's loads before the phase part of block c
-#endif
-#ifndef PSK_WAVES_H1
-#define PSK_WAVES_H1 4  // waves per SIMD the H = 1 instantiations are register-limited to
-#endif
-constexpr int kR = 2;             // symbols per lane per block
-constexpr int kB = kWave * kR;    // symbols per block
+constexpr int kR = 2;           // symbols per lane per block
+constexpr int kB = kWave * kR;  // symbols per block
+constexpr int kMaxUnwrapPasses = 160;
+constexpr int kScreenRefresh = 64;  // blocks between refreshes of the float window sums
 
 struct FastCarry {
     double ySum, xySum;    // LinearFit sums after the last processed symbol
     float est;             // phaseEstimate
     float last_re, last_im;
     float den, xavg;       // LinearFit::denominator / xAvg
-    float m, b;
+    float m, b;            // scratch for the prologue / epilogue fits
     uint32_t q;            // number of values ever written to the LDS y ring (history included)
     uint32_t last_k;       // timing index of the last emitted symbol (prediction seed)
     unsigned umax, umin1;  // exactness guard: max energy bits, min (energy bits - 1)
     bool refuse;
-    uint32_t stat_blocks, stat_extra;
+    uint32_t stat_blocks, stat_extra, stat_exact_blocks;
 };
 
 // exactness guard bookkeeping: max of the energy bit patterns and min of (bits - 1); a zero
@@ -54,17 +64,15 @@ PSK_DEV void guard_track(FastCarry &cy, float e)
 // what a block keeps of the symbols it loaded (positions s = 2*lane + r)
 template <int S>
 struct BlockKeep {
-    float e[kR][S];   // energies
-    float2 pk[kR];    // the sample at the predicted timing index
-    int kp[kR];       // the predicted timing index
+    float e[kR][S];  // energies
+    float2 pk[kR];   // the sample at the predicted timing index
+    int kp[kR];      // the predicted timing index
 };
 
-PSK_DEV float bperm(int src_lane, float v)
+PSK_DEV float bperm_addr(int addr, float v)
 {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
 }
-PSK_DEV int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-PSK_DEV float bperm_addr(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
 PSK_DEV int bperm_addr(int addr, int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
 
 // Cross-lane fetch of "the value that sat D symbol positions earlier in the stream of loaded
@@ -73,10 +81,10 @@ PSK_DEV int bperm_addr(int addr, int v) { return __builtin_amdgcn_ds_bpermute(ad
 // block c-u ("newer"), the others in block c-u-1 ("older").  The per-lane parameters depend only
 // on numAvg, so they are computed once per call; the fetch itself is branch-free.
 struct RotParam {
-    int u;            // how many blocks back "newer" is (wave-uniform)
-    bool odd;         // v odd: the two slots of a lane swap roles
-    int src_addr[kR]; // byte address (lane*4) this lane pulls slot r from
-    bool offer_old[kR];  // what this lane offers for the puller of its slot r: older or newer block
+    int u;               // how many blocks back "newer" is (wave-uniform)
+    bool odd;            // v odd: the two slots of a lane swap roles
+    int src_addr[kR];    // byte address (lane*4) this lane pulls slot r from
+    bool offer_old[kR];  // what this lane offers to the puller of its slot r: older or newer block
 };
 PSK_DEV RotParam rot_param(int lane, unsigned D)
 {
@@ -88,10 +96,8 @@ PSK_DEV RotParam rot_param(int lane, unsigned D)
 #pragma unroll
     for (int r = 0; r < kR; r++) {
         p.src_addr[r] = ((((2 * lane + r - v) & (kB - 1)) >> 1)) << 2;
-        const int r_src = r ^ (int)p.odd;  // the slot of the source lane that is read for result r
-        (void)r_src;
-        // this lane's slot q is pulled by result r = q ^ odd of some lane; that puller needs the
-        // older block iff its own position < v, i.e. iff this slot's position >= kB - v
+        // this lane's slot r is pulled by some lane's result r ^ odd; that puller needs the older
+        // block iff its own position < v, i.e. iff this slot's position >= kB - v
         p.offer_old[r] = (2 * lane + r) >= kB - v;
     }
     return p;
@@ -99,15 +105,14 @@ PSK_DEV RotParam rot_param(int lane, unsigned D)
 template <class T>
 PSK_DEV T rot_pull(const RotParam &p, int r, const T (&newer)[kR], const T (&older)[kR])
 {
-    // slot of the source lane read for result r (compile-time indices only: no scratch)
+    // compile-time array indices only (a runtime index would push the arrays to scratch)
     const T off0 = p.offer_old[0] ? older[0] : newer[0];
     const T off1 = p.offer_old[1] ? older[1] : newer[1];
     const T offered = (r == 0) ? (p.odd ? off1 : off0) : (p.odd ? off0 : off1);
     return bperm_addr(p.src_addr[r], offered);
 }
 
-// x[k] for a per-lane k without a runtime-indexed array (which would live in scratch): a
-// binary tree of selects over compile-time indices
+// x[k] for a per-lane k without a runtime-indexed array: a binary tree of selects
 template <int S, int LO, int SPAN>
 PSK_DEV float sel_tree(const float2 (&x)[S], int k, bool want_y)
 {
@@ -136,21 +141,69 @@ PSK_DEV float2 select_sample(const float2 (&x)[S], int k)
 // tau = kB*cblk + s + A - 1; symbols outside [tau_lo, tau_hi] are zero-filled
 template <int S>
 PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long tau_lo, long long tau_hi, int lane,
-                        float2 (&x)[kR][S], bool (&ok)[kR])
+                        float2 (&x)[kR][S])
 {
 #pragma unroll
     for (int r = 0; r < kR; r++) {
         const long long tau = cblk * kB + 2 * lane + r + (long long)A - 1;
-        ok[r] = tau >= tau_lo && tau <= tau_hi;
-        load_symbol<S>(X, (uint64_t)(ok[r] ? tau : 0), ok[r], x[r]);
+        const bool ok = tau >= tau_lo && tau <= tau_hi;
+        load_symbol<S>(X, (uint64_t)(ok ? tau : 0), ok, x[r]);
     }
 }
 
+// Parking of the kept block in LDS while the phase part of the loop runs (numAvg <= 128 only:
+// frees its 6 + 2S registers where the register budget is tightest).  Layout [field][lane].
+template <int S>
+PSK_DEV void park_block(float *park, int lane, const BlockKeep<S> &b)
+{
+    int f = 0;
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+#pragma unroll
+        for (int k = 0; k < S; k++) park[(f++) * kWave + lane] = b.e[r][k];
+        park[(f++) * kWave + lane] = b.pk[r].x;
+        park[(f++) * kWave + lane] = b.pk[r].y;
+        park[(f++) * kWave + lane] = __int_as_float(b.kp[r]);
+    }
+}
+template <int S>
+PSK_DEV void unpark_block(const float *park, int lane, BlockKeep<S> &b)
+{
+    int f = 0;
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+#pragma unroll
+        for (int k = 0; k < S; k++) b.e[r][k] = park[(f++) * kWave + lane];
+        b.pk[r].x = park[(f++) * kWave + lane];
+        b.pk[r].y = park[(f++) * kWave + lane];
+        b.kp[r] = __float_as_int(park[(f++) * kWave + lane]);
+    }
+}
+constexpr int park_floats(int S) { return kR * (S + 3) * kWave; }
+
+// value of `field` in the block `back` blocks back in time (0 = cur, j >= 1 = hist[j-1]); back is
+// wave-uniform and at most H
+template <int S, int H, class F>
+PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&hist)[H], F field)
+{
+    auto v = field(back == 0 ? cur : hist[0]);
+#pragma unroll
+    for (int j = 2; j <= H; j++)
+        if (back == j)
+            v = field(hist[j - 1]);
+    return v;
+}
+
 // One block (128 symbols) of the feedback unwrap + LinearFit::next recurrence
-// (cpp/psk_soft.cpp:477-482, 48-87, 135-174).  WARM = the fit window is still growing somewhere in
-// the block (first phaseAvg symbols after a history clear): per-lane window sizes and denominators.
-// Returns the number of extra fixed-point passes; den_last / xavg_last = LinearFit::denominator /
-// xAvg after the block's last valid symbol.
+// (reference cpp/psk_soft.cpp:477-482, 48-87, 135-174).  The recurrence
+//     est[i-1] -> numWraps[i] -> y[i] -> (ySum, xySum) -> est[i]
+// is solved for all positions at once: numWraps is speculated by consecutive differences, the
+// sums are two double prefix scans over y[i] - y[i-n] and term[i] - xdelta*ySum'[i] with the
+// reference's float-rounded term[i] (quirk Q4), and every position re-derives numWraps from its
+// predecessor's estimate exactly as :477 does; disagreements repeat the pass, each pass fixes at
+// least one more position.  WARM = the fit window is still growing somewhere in the block.
+// Returns the number of extra passes; den_last / xavg_last = LinearFit::denominator / xAvg after
+// the block's last valid symbol.
 template <bool WARM>
 PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, double rden_s,
                       double rpts_s, const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
@@ -159,7 +212,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
 {
     uint32_t before[kR];
     bool steady[kR];
-    float sizef[kR];   // (float)yvals.size() at cpp/psk_soft.cpp:78
+    float sizef[kR];  // (float)yvals.size() at cpp/psk_soft.cpp:78
     uint32_t pts[kR];
     float den_l[kR], xavg_l[kR];
 #pragma unroll
@@ -184,10 +237,12 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
     // speculate numWraps by consecutive differences; position 0 is exact (carried estimate)
     int w[kR];
     {
-        double raw_prev0 = wave_up1(rawd[1], rawd[1]);
-        int dl0 = (lane == 0) ? (int)unwrap_count(cy.est, rawd[0])
-                              : (int)to_long_x86(__builtin_round((raw_prev0 - rawd[0]) * kInvTwoPi));
-        int dl1 = (int)to_long_x86(__builtin_round((rawd[0] - rawd[1]) * kInvTwoPi));
+        // (a guess only: float arithmetic is enough; every count is verified below)
+        const float rf0 = (float)rawd[0], rf1 = (float)rawd[1];
+        const float rprev = wave_up1(rf1, rf1);
+        const float inv2pi = 0.15915494f;
+        int dl0 = (lane == 0) ? (int)unwrap_count(cy.est, rawd[0]) : (int)__builtin_rintf((rprev - rf0) * inv2pi);
+        int dl1 = (int)__builtin_rintf((rf0 - rf1) * inv2pi);
         int incl = wave_scan_i32(dl0 + dl1);
         w[1] = incl;
         w[0] = incl - dl1;
@@ -200,7 +255,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             double yd = rawd[r] + (double)(long long)w[r] * kTwoPi;  // cpp/psk_soft.cpp:478
             y[r] = (float)yd;                                         // next(float yval), :481
             if (valid[r])
-                yring[(before[r]) & kYMask] = y[r];
+                yring[before[r] & kYMask] = y[r];
             y_d[r] = (double)y[r];  // (positions past the end only feed sums past the end)
         }
         wave_lds_fence();
@@ -238,6 +293,16 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             }
         }
         float est_prev0 = wave_up1(est[1], cy.est);
+        {
+            // round((est_prev - raw)/2pi) == w  <=>  |est_prev - (raw + 2 pi w)| < pi; with the
+            // unwrapped value y within 3.0 of the feedback (and small enough that its float
+            // rounding is far below the 0.14 of slack) no exact quotient is needed
+            const float g0 = __builtin_fabsf(est_prev0 - y[0]), g1 = __builtin_fabsf(est[0] - y[1]);
+            const bool sure0 = !valid[0] || (g0 < 3.0f && __builtin_fabsf(y[0]) < 65536.0f);
+            const bool sure1 = !valid[1] || (g1 < 3.0f && __builtin_fabsf(y[1]) < 65536.0f);
+            if (__all(sure0 && sure1))
+                break;
+        }
         int w2_0 = (int)unwrap_count(est_prev0, rawd[0]);  // cpp/psk_soft.cpp:477 with the true feedback
         int w2_1 = (int)unwrap_count(est[0], rawd[1]);
         bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
@@ -245,7 +310,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             break;
         w[0] = w2_0;
         w[1] = w2_1;
-        if (++pass > 2 * kMaxUnwrapPasses)
+        if (++pass > kMaxUnwrapPasses)
             break;
     }
     if (WARM) {
@@ -255,21 +320,28 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
     return pass;
 }
 
-// block j back in time: 0 = the block being processed, j >= 1 = hist[j-1]; u is wave-uniform
-template <int S, int H, class F>
-PSK_DEV float pick_block_e(int u, const BlockKeep<S> &cur, const BlockKeep<S> (&hist)[H], int older, F field)
+// float window sum W_k at the LAST position of the newest kept block (= the carry into the next
+// block), recomputed from the energies in registers: the A = u*kB + v symbols ending there are
+// the u newest blocks whole plus the positions >= kB - v of the one before
+template <int S, int H>
+PSK_DEV float window_end_f32(const BlockKeep<S> (&hist)[H], uint32_t A, int lane, int k)
 {
-    // value of `field` in block (u + older) back
-    float v = field(u + older == 0 ? cur : hist[0]);
+    const int u = (int)((A - 1) / kB), v = (int)A - u * kB;  // 1 <= v <= kB
+    float acc = 0.0f;
 #pragma unroll
-    for (int j = 1; j <= H; j++)
-        if (u + older == j)
-            v = field(hist[j - 1 < H ? j - 1 : H - 1]);
-    return v;
+    for (int j = 0; j < H; j++) {
+        const bool whole = (H > 1) && j < u;
+        const bool part = (H == 1) ? true : j == u;
+#pragma unroll
+        for (int r = 0; r < kR; r++)
+            if (whole || (part && 2 * lane + r >= kB - v))
+                acc += hist[j].e[r][k];
+    }
+    return read_lane(wave_scan_f32(acc), 63);
 }
 
-template <int S, int H>
-PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, FastCarry &cy)
+template <int S, int H, bool EXACT>
+PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *park, FastCarry &cy)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t A = p.A, M = p.M, n = p.lf_n;
@@ -278,9 +350,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
     const long long tau_last = (long long)n_out + (long long)A - 2;  // newest symbol any emitted window uses
 
     // ---- prologue: the first A-1 symbols (the carried window) as "blocks" -H .. -1:
-    //      W_k(-1) = their energy sums (= resyncEnergy, cpp/psk_soft.cpp:619-636) ----
+    //      W_k(-1) = their energy sums (= resyncEnergy, reference cpp/psk_soft.cpp:619-636) ----
     BlockKeep<S> hist[H];
-    double Wc[S];
+    double Wc[S];  // EXACT: the exact carried window sums
+    float Wf[S];   // screened: their float shadow
     {
         double acc[S];
 #pragma unroll
@@ -288,14 +361,14 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
 #pragma unroll
         for (int h = H - 1; h >= 0; h--) {
             float2 x[kR][S];
-            bool ok[kR];
-            load_block<S>(X, -(long long)(h + 1), A, 0, (long long)A - 2, lane, x, ok);
+            load_block<S>(X, -(long long)(h + 1), A, 0, (long long)A - 2, lane, x);
 #pragma unroll
             for (int r = 0; r < kR; r++) {
 #pragma unroll
                 for (int k = 0; k < S; k++) {
                     float e = norm_f(x[r][k].x, x[r][k].y);
-                    guard_track(cy, e);  // zero-filled (absent) symbols are neutral
+                    if (EXACT)
+                        guard_track(cy, e);  // zero-filled (absent) symbols are neutral
                     hist[h].e[r][k] = e;
                     acc[k] += (double)e;
                 }
@@ -304,13 +377,29 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             }
         }
 #pragma unroll
-        for (int k = 0; k < S; k++) Wc[k] = wave_sum_f64(acc[k]);
+        for (int k = 0; k < S; k++) {
+            Wc[k] = wave_sum_f64(acc[k]);
+            Wf[k] = (float)Wc[k];
+        }
     }
+    // error bound of the float shadow (screened path)
+    const float kU = 5.9604645e-08f;  // 2^-24
+    float wmax_prev = 0.0f;
+#pragma unroll
+    for (int k = 0; k < S; k++) wmax_prev = __builtin_fmaxf(wmax_prev, Wf[k]);
+    float err_c = 2.0f * kU * wmax_prev;
+    // rounding-error budget of one screened block, relative to the largest window sum in play:
+    // the local roundings of up to 2*(128/A+1) window-loads of energy pass through the scan, plus
+    // the scan's own additions and the carry
+    const float c_blk = kU * (64.0f + 16.0f * ((float)kB / (float)A + 1.0f));
+    int since_refresh = 0;
 
     // cross-lane fetch parameters: energies leave the window A symbols after they entered it;
     // the picked-from symbol entered it A-1 symbols ago
     const RotParam rotE = rot_param(lane, A);
     const RotParam rotP = rot_param(lane, A - 1);
+    // (numAvg <= 128: both fetches reach at most one block back, known at compile time)
+    const int uE = (H == 1) ? 0 : rotE.u, uP = (H == 1) ? 0 : rotP.u;
 
     // steady-state fit constants
     float den_s = cy.den, xavg_s = cy.xavg;
@@ -321,18 +410,25 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
     const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
     const float inv_M = 1.0f / (float)(M ? M : 1);
 
+    if constexpr (!EXACT) {
+        // the screened kernel is specialised for the steady state: a call that starts with the fit
+        // window still filling (first phaseAvg symbols after a history clear) goes to the exact kernel
+        if (cy.q < n) {
+            cy.refuse = true;
+            return;
+        }
+    }
     const int n_blocks = (n_out + kB - 1) / kB;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
-    float2 xn[kR][S];
-    bool okn[kR];
-#if PSK_PREFETCH
-    load_block<S>(X, 0, A, 0, tau_last, lane, xn, okn);
-#endif
+
+    if constexpr (H == 1)
+        park_block<S>(park, lane, hist[0]);
 
     for (int c = 0; c < n_blocks; c++) {
-#if !PSK_PREFETCH
-        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn, okn);
-#endif
+        float2 xn[kR][S];
+        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+        if constexpr (H == 1)
+            unpark_block<S>(park, lane, hist[0]);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -349,7 +445,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
 #pragma unroll
             for (int k = 0; k < S; k++) {
                 float e = norm_f(xn[r][k].x, xn[r][k].y);
-                guard_track(cy, e);
+                if (EXACT)
+                    guard_track(cy, e);
                 cur.e[r][k] = e;
             }
             cur.kp[r] = kpred[r];
@@ -363,8 +460,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             float nw[kR], od[kR];
 #pragma unroll
             for (int rr = 0; rr < kR; rr++) {
-                nw[rr] = pick_block_e<S, H>(rotE.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
-                od[rr] = pick_block_e<S, H>(rotE.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                nw[rr] = block_back<S, H>(uE, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                od[rr] = block_back<S, H>(uE + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
             }
 #pragma unroll
             for (int r = 0; r < kR; r++) e_old[r][k] = rot_pull<float>(rotE, r, nw, od);
@@ -377,12 +474,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             int nk[kR], ok2[kR];
 #pragma unroll
             for (int rr = 0; rr < kR; rr++) {
-                nx[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
-                ox[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
-                ny[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
-                oy[rr] = pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
-                nk[rr] = __float_as_int(pick_block_e<S, H>(rotP.u, cur, hist, 0, [&](const BlockKeep<S> &b) { return __int_as_float(b.kp[rr]); }));
-                ok2[rr] = __float_as_int(pick_block_e<S, H>(rotP.u, cur, hist, 1, [&](const BlockKeep<S> &b) { return __int_as_float(b.kp[rr]); }));
+                nx[rr] = block_back<S, H>(uP, cur, hist, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
+                ox[rr] = block_back<S, H>(uP + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.pk[rr].x; });
+                ny[rr] = block_back<S, H>(uP, cur, hist, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
+                oy[rr] = block_back<S, H>(uP + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.pk[rr].y; });
+                nk[rr] = block_back<S, H>(uP, cur, hist, [&](const BlockKeep<S> &b) { return b.kp[rr]; });
+                ok2[rr] = block_back<S, H>(uP + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.kp[rr]; });
             }
 #pragma unroll
             for (int r = 0; r < kR; r++) {
@@ -392,34 +489,83 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             }
         }
 
-        double bestW[kR] = {0.0, 0.0};
         int bestK[kR] = {0, 0};
+        if constexpr (!EXACT) {
+            // ---- screening pass in float ----
+            float b1[kR], b2[kR];  // best and second-best window sum
 #pragma unroll
-        for (int k = 0; k < S; k++) {
-            // positions past the end of the call only pollute sums of later positions, which are
-            // past the end too: no masking needed
-            double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
-            double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
-            double t1 = d0 + d1;                        // exact: float-valued addends (Q8)
-            double incl = wave_scan_f64(t1);
-            double W1 = Wc[k] + incl;                   // window sum of the lane's second symbol
-            double W0 = W1 - d1;                        // ... and of its first (exact)
-            Wc[k] = read_lane(W1, 63);
-            // std::max_element: first maximum, strict '<' (cpp/psk_soft.cpp:462)
-            if (k == 0) {
-                bestW[0] = W0;
-                bestW[1] = W1;
-            } else {
-                if (bestW[0] < W0) {
+            for (int k = 0; k < S; k++) {
+                float d0 = cur.e[0][k] - e_old[0][k];
+                float d1 = cur.e[1][k] - e_old[1][k];
+                float incl = wave_scan_f32(d0 + d1);
+                float W1 = Wf[k] + incl;
+                float W0 = W1 - d1;
+                Wf[k] = read_lane(W1, 63);
+                if (k == 0) {
+                    b1[0] = W0;
+                    b1[1] = W1;
+                    b2[0] = -__builtin_inff();
+                    b2[1] = -__builtin_inff();
+                } else {
+                    const bool g0 = W0 > b1[0], g1 = W1 > b1[1];
+                    b2[0] = g0 ? b1[0] : __builtin_fmaxf(b2[0], W0);
+                    b2[1] = g1 ? b1[1] : __builtin_fmaxf(b2[1], W1);
+                    b1[0] = g0 ? W0 : b1[0];
+                    b1[1] = g1 ? W1 : b1[1];
+                    bestK[0] = g0 ? k : bestK[0];
+                    bestK[1] = g1 ? k : bestK[1];
+                }
+            }
+            const float wmax = __builtin_fmaxf(wave_max_f32(__builtin_fmaxf(b1[0], b1[1])), wmax_prev);
+            const float e_blk = c_blk * wmax;
+            const float thr = 2.0f * (err_c + e_blk);
+            // (NaN / inf anywhere makes the comparison false)
+            const bool ok0 = !valid[0] || ((b1[0] - b2[0]) > thr), ok1 = !valid[1] || ((b1[1] - b2[1]) > thr);
+            err_c += e_blk;
+            wmax_prev = wmax;
+            since_refresh++;
+            const bool refuse_now = !__all(ok0 && ok1);
+            if (refuse_now) {  // a near-tie (or a non-finite energy): leave the call to the exact kernel
+                cy.refuse = true;
+                return;
+            }
+        } else {
+            // ---- exact pass: float-valued addends summed in double ----
+            double bestW[kR] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                // (positions past the end of the call only pollute sums of later positions, which
+                // are past the end too: no masking needed)
+                double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
+                double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
+                double incl = wave_scan_f64(d0 + d1);  // exact (quirk Q8)
+                double W1 = Wc[k] + incl;              // window sum of the lane's second symbol
+                double W0 = W1 - d1;                   // ... and of its first (exact)
+                Wc[k] = read_lane(W1, 63);
+                // std::max_element: first maximum, strict '<' (reference cpp/psk_soft.cpp:462)
+                if (k == 0 || bestW[0] < W0) {
                     bestW[0] = W0;
                     bestK[0] = k;
                 }
-                if (bestW[1] < W1) {
+                if (k == 0 || bestW[1] < W1) {
                     bestW[1] = W1;
                     bestK[1] = k;
                 }
             }
+            cy.stat_exact_blocks += 1;
         }
+
+        // sampleIndex_dataShort_out (reference cpp/psk_soft.cpp:466) goes out at once
+        if (p.sidx) {
+            typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
+            if (valid[1]) {
+                s2u v = {(short)(unsigned short)bestK[0], (short)(unsigned short)bestK[1]};
+                *reinterpret_cast<s2u *>(p.sidx + i0) = v;
+            } else if (valid[0]) {
+                p.sidx[i0] = (int16_t)(unsigned short)bestK[0];
+            }
+        }
+        cy.last_k = (uint32_t)__builtin_amdgcn_readlane(r_last ? bestK[1] : bestK[0], lane_last);
 
         // the sample to output: kept at a predicted index -- verify, else re-read (rare, exact either way)
         cf32 s[kR];
@@ -440,12 +586,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
 #pragma unroll
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;
-#if PSK_PREFETCH
-        // prefetch the next block's symbols: their latency hides under the phase part below
-        load_block<S>(X, (long long)c + 1, A, 0, tau_last, lane, xn, okn);
-#endif
+        if constexpr (H == 1)
+            park_block<S>(park, lane, cur);  // not needed again before the next block
 
-        // ================= raw phase: arg(pow(sample, M)) (cpp/psk_soft.cpp:474) =================
+        // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
         double rawd[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
@@ -461,19 +605,19 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
         double ySum_l[kR], xySum_l[kR];
         float den_last = den_s, xavg_last = xavg_s;
         int pass;
-        if (__builtin_expect(q0 >= n, 1)) {
+        if (!EXACT || __builtin_expect(q0 >= n, 1)) {
             pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
                                     xySum_l, lane_last, r_last, den_last, xavg_last);
-        } else {
+        } else {  // (the screened kernel never gets here: it leaves warm-up calls to this one)
             pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
                                    xySum_l, lane_last, r_last, den_last, xavg_last);
         }
-        if (pass > 2 * kMaxUnwrapPasses)
+        if (pass > kMaxUnwrapPasses)
             cy.refuse = true;
         cy.stat_blocks += 1;
         cy.stat_extra += (uint32_t)pass;
 
-        // ================= de-rotation and hard decisions (cpp/psk_soft.cpp:484-566) =================
+        // ================= de-rotation and hard decisions (reference cpp/psk_soft.cpp:484-566) =================
         cf32 corr[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
@@ -515,10 +659,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
                 f2u v = {est[0], est[1]};
                 *reinterpret_cast<f2u *>(p.phase + i0) = v;
             }
-            if (p.sidx) {
-                s2u v = {(short)(unsigned short)bestK[0], (short)(unsigned short)bestK[1]};
-                *reinterpret_cast<s2u *>(p.sidx + i0) = v;
-            }
             if (!p.bits) {
             } else if (p.bpb == 1) {
                 s2u v = {(short)(corr[0].re < 0), (short)(corr[1].re < 0)};
@@ -542,8 +682,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
                 reinterpret_cast<float2 *>(p.soft)[i0] = make_float2(corr[0].re, corr[0].im);
             if (p.phase)
                 p.phase[i0] = est[0];
-            if (p.sidx)
-                p.sidx[i0] = (int16_t)(unsigned short)bestK[0];
             if (!p.bits) {
             } else if (p.bpb == 1) {
                 p.bits[i0] = (int16_t)(corr[0].re < 0);
@@ -566,13 +704,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             const float e_ = r_last ? est[1] : est[0];
             const float sre = r_last ? s[1].re : s[0].re;
             const float sim = r_last ? s[1].im : s[0].im;
-            const int kk = r_last ? bestK[1] : bestK[0];
             cy.ySum = read_lane(ys, lane_last);
             cy.xySum = read_lane(xys, lane_last);
             cy.est = read_lane(e_, lane_last);
             cy.last_re = read_lane(sre, lane_last);
             cy.last_im = read_lane(sim, lane_last);
-            cy.last_k = (uint32_t)__builtin_amdgcn_readlane(kk, lane_last);
             const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
             if (pts_last > 1) {  // calculateDenominator ran for the window size reached (cpp/psk_soft.cpp:81-83)
                 cy.den = den_last;
@@ -580,6 +716,22 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, Fas
             }
         }
         cy.q = q0 + (uint32_t)nvalid;
+
+        if constexpr (!EXACT) {
+            // every kScreenRefresh blocks recompute the float window sums from the energies in
+            // registers, so that their error bound does not grow with the length of the call
+            if (since_refresh >= kScreenRefresh) {
+                float wm = 0.0f;
+#pragma unroll
+                for (int k = 0; k < S; k++) {
+                    Wf[k] = window_end_f32<S, H>(hist, A, lane, k);
+                    wm = __builtin_fmaxf(wm, Wf[k]);
+                }
+                wmax_prev = __builtin_fmaxf(wmax_prev, wm);
+                err_c = 16.0f * kU * wmax_prev;  // a 7-level float tree sum of non-negative terms
+                since_refresh = 0;
+            }
+        }
     }
 }
 

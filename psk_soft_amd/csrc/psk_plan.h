@@ -70,7 +70,7 @@ struct ChanState {
     uint32_t stat_blocks;
     uint32_t stat_extra;
     uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
-    uint32_t pad;
+    uint32_t stat_exact;  // blocks whose timing argmax needed the exact double-precision pass
 };
 
 }  // namespace psk

@@ -1,0 +1,214 @@
+// psk_wave.h -- wave64 cross-lane primitives (DPP), the virtual sample stream of a call, and the
+// LinearFit sum rebuild shared by the gfx950 kernels of the psk_soft hot path.
+#ifndef PSK_WAVE_H
+#define PSK_WAVE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "psk_device_math.h"
+#include "psk_plan.h"
+
+namespace psk {
+
+constexpr int kWave = 64;
+constexpr int kYRing = 512;         // LDS ring of unwrapped phases per wave (floats)
+constexpr int kYMask = kYRing - 1;
+constexpr int kSeqMaxS = 1024;      // reference-order kernel: symbolEnergy[] lives in LDS
+constexpr int kSeqChunk = 512;      // reference-order kernel: packet staging chunk (complex samples)
+
+// ---------------------------------------------------------------------------------
+// cross-lane primitives (wave64, DPP)
+// ---------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+PSK_DEV int dpp_zero(int v)
+{
+    // lanes without a source lane, and rows masked off, receive 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+PSK_DEV double dpp_zero_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = dpp_zero<CTRL, ROW_MASK>(lo);
+    hi = dpp_zero<CTRL, ROW_MASK>(hi);
+    return __hiloint2double(hi, lo);
+}
+// row_shr:N with bound_ctrl:0 -- lanes whose source falls outside their row of 16 read 0, so no
+// "old" value has to be materialised (saves two v_mov per 64-bit step)
+template <int CTRL>
+PSK_DEV int dpp_shr0(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+PSK_DEV double dpp_shr0_f64(double v)
+{
+    int lo = dpp_shr0<CTRL>(__double2loint(v)), hi = dpp_shr0<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 inside each row of 16, then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+PSK_DEV double wave_scan_f64(double v)
+{
+    v += dpp_shr0_f64<0x111>(v);
+    v += dpp_shr0_f64<0x112>(v);
+    v += dpp_shr0_f64<0x114>(v);
+    v += dpp_shr0_f64<0x118>(v);
+    v += dpp_zero_f64<0x142, 0xA>(v);
+    v += dpp_zero_f64<0x143, 0xC>(v);
+    return v;
+}
+// float versions: the adds / maxes fold their DPP source (one instruction a step)
+template <int CTRL>
+PSK_DEV float dpp_shr0_f32(float v)
+{
+    return __int_as_float(dpp_shr0<CTRL>(__float_as_int(v)));
+}
+PSK_DEV float wave_scan_f32(float v)
+{
+    v += dpp_shr0_f32<0x111>(v);
+    v += dpp_shr0_f32<0x112>(v);
+    v += dpp_shr0_f32<0x114>(v);
+    v += dpp_shr0_f32<0x118>(v);
+    v += __int_as_float(dpp_zero<0x142, 0xA>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero<0x143, 0xC>(__float_as_int(v)));
+    return v;
+}
+// max over the wave of non-negative values: lanes without a source read 0, so the running
+// maximum of lane 63 is the wave maximum
+PSK_DEV float wave_max_f32(float v)
+{
+    v = __builtin_fmaxf(v, dpp_shr0_f32<0x111>(v));
+    v = __builtin_fmaxf(v, dpp_shr0_f32<0x112>(v));
+    v = __builtin_fmaxf(v, dpp_shr0_f32<0x114>(v));
+    v = __builtin_fmaxf(v, dpp_shr0_f32<0x118>(v));
+    v = __builtin_fmaxf(v, __int_as_float(dpp_zero<0x142, 0xA>(__float_as_int(v))));
+    v = __builtin_fmaxf(v, __int_as_float(dpp_zero<0x143, 0xC>(__float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+PSK_DEV int wave_scan_i32(int v)
+{
+    v += dpp_shr0<0x111>(v);
+    v += dpp_shr0<0x112>(v);
+    v += dpp_shr0<0x114>(v);
+    v += dpp_shr0<0x118>(v);
+    v += dpp_zero<0x142, 0xA>(v);
+    v += dpp_zero<0x143, 0xC>(v);
+    return v;
+}
+// value of lane-1 (wave_shr:1); lane 0 receives `carry`
+PSK_DEV int wave_up1(int v, int carry) { return __builtin_amdgcn_update_dpp(carry, v, 0x138, 0xF, 0xF, false); }
+PSK_DEV float wave_up1(float v, float carry)
+{
+    return __int_as_float(wave_up1(__float_as_int(v), __float_as_int(carry)));
+}
+PSK_DEV double wave_up1(double v, double carry)
+{
+    int lo = wave_up1(__double2loint(v), __double2loint(carry));
+    int hi = wave_up1(__double2hiint(v), __double2hiint(carry));
+    return __hiloint2double(hi, lo);
+}
+PSK_DEV float read_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+PSK_DEV double read_lane(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+PSK_DEV double wave_sum_f64(double v) { return read_lane(wave_scan_f64(v), 63); }
+PSK_DEV unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        unsigned t = (unsigned)__shfl_xor((int)v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+PSK_DEV unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        unsigned t = (unsigned)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+// orders LDS traffic of this wave: a later ds_read sees an earlier ds_write of another lane
+PSK_DEV void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------
+// the virtual stream X = [ring of carried samples] ++ [packet]   (the `samples` deque)
+// ---------------------------------------------------------------------------------
+struct XView {
+    const float2 *ring;
+    const float2 *in;
+    uint32_t L0;  // samples in the ring
+};
+PSK_DEV float2 x_at(const XView &X, uint64_t j) { return j < X.L0 ? X.ring[j] : X.in[j - X.L0]; }
+
+template <int S>
+PSK_DEV void load_symbol(const XView &X, uint64_t tau, bool valid, float2 (&x)[S])
+{
+#pragma unroll
+    for (int k = 0; k < S; k++) x[k] = make_float2(0.0f, 0.0f);
+    if (!valid)
+        return;
+    const uint64_t j0 = tau * (uint64_t)S;
+    const float2 *p;
+    if (j0 >= X.L0) {
+        p = X.in + (j0 - X.L0);
+    } else if (j0 + S <= X.L0) {
+        p = X.ring + j0;
+    } else {  // the one symbol that straddles ring and packet
+#pragma unroll
+        for (int k = 0; k < S; k++) x[k] = x_at(X, j0 + k);
+        return;
+    }
+    if (S % 2 == 0) {
+        // 16-byte loads; the address is only 8-byte aligned (gfx950 global loads allow that)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+        const f4u *q = reinterpret_cast<const f4u *>(p);
+#pragma unroll
+        for (int k = 0; k < S / 2; k++) {
+            f4u t = q[k];
+            x[2 * k] = make_float2(t.x, t.y);
+            x[2 * k + 1] = make_float2(t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; k++) x[k] = p[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// LinearFit pieces shared by both kernels
+// ---------------------------------------------------------------------------------
+// LinearFit::reset() tail (cpp/psk_soft.cpp:110-122) on `len` values y(j), wave-parallel:
+// ySum = sum y_j, xySum = sum fl32(fl32(j*xdelta)*y_j) accumulated in double.
+template <class YAt>
+PSK_DEV void fit_rebuild_sums(YAt y_at, uint32_t len, float xdelta, double &ySum, double &xySum)
+{
+    const int lane = threadIdx.x & 63;
+    double ys = 0.0, xys = 0.0;
+    for (uint32_t j = lane; j < len; j += kWave) {
+        float y = y_at(j);
+        ys += (double)y;
+        float jx = (float)j * xdelta;
+        float jxy = jx * y;
+        xys += (double)jxy;
+    }
+    ySum = wave_sum_f64(ys);
+    xySum = wave_sum_f64(xys);
+}
+
+// ---------------------------------------------------------------------------------
+// wave-scan kernel
+// ---------------------------------------------------------------------------------
+}  // namespace psk
+#endif

@@ -82,10 +82,12 @@ class Output(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [
         ("channels_fast", ctypes.c_uint64),
+        ("channels_exact_timing", ctypes.c_uint64),
         ("channels_sequential", ctypes.c_uint64),
         ("channels_guard", ctypes.c_uint64),
         ("unwrap_extra_passes", ctypes.c_uint64),
         ("unwrap_blocks", ctypes.c_uint64),
+        ("timing_exact_blocks", ctypes.c_uint64),
     ]
 
 
