@@ -33,6 +33,12 @@
 
 namespace psk {
 
+#ifndef PSK_REFUSE_EARLY_EXIT
+#define PSK_REFUSE_EARLY_EXIT 1
+#endif
+#ifndef PSK_PARK
+#define PSK_PARK 1
+#endif
 constexpr int kR = 2;           // symbols per lane per block
 constexpr int kB = kWave * kR;  // symbols per block
 constexpr int kMaxUnwrapPasses = 160;
@@ -421,13 +427,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     const int n_blocks = (n_out + kB - 1) / kB;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
-    if constexpr (H == 1)
+    if constexpr (H == 1 && PSK_PARK)
         park_block<S>(park, lane, hist[0]);
 
     for (int c = 0; c < n_blocks; c++) {
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
-        if constexpr (H == 1)
+        if constexpr (H == 1 && PSK_PARK)
             unpark_block<S>(park, lane, hist[0]);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
@@ -524,11 +530,15 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             err_c += e_blk;
             wmax_prev = wmax;
             since_refresh++;
-            const bool refuse_now = !__all(ok0 && ok1);
-            if (refuse_now) {  // a near-tie (or a non-finite energy): leave the call to the exact kernel
+            // a near-tie (or a non-finite energy) anywhere: the call goes to the exact kernel
+#if PSK_REFUSE_EARLY_EXIT
+            if (!__all(ok0 && ok1)) {
                 cy.refuse = true;
                 return;
             }
+#else
+            cy.refuse = cy.refuse || !(ok0 && ok1);  // (nothing is committed; the wave just runs on)
+#endif
         } else {
             // ---- exact pass: float-valued addends summed in double ----
             double bestW[kR] = {0.0, 0.0};
@@ -586,7 +596,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 #pragma unroll
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;
-        if constexpr (H == 1)
+        if constexpr (H == 1 && PSK_PARK)
             park_block<S>(park, lane, cur);  // not needed again before the next block
 
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================

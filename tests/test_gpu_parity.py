@@ -175,6 +175,91 @@ def test_edge_packets(oracle_mod):
     h.close()
 
 
+def test_tie_heavy_signal_takes_the_exact_timing_kernel(oracle_mod):
+    """Rectangular pulses (the reference test's own stimulus): every intra-symbol phase has the
+    same energy up to noise, the float screening cannot vouch for the argmax and must hand the
+    call to the exact-timing kernel, whose first-maximum tie rule has to match the reference."""
+    import random as _random
+
+    from psk_soft_amd.stimulus import gen_psk
+
+    data, _ = gen_psk(3000, samp_per_baud=8, num_syms=4, differential=False, rng=_random.Random(11))
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100)
+    ref = oracle_run(oracle_mod, data, props, packet=8192)
+    h = _handle()
+    h.configure(0, [props])
+    got = run_gpu(h, 0, data, 0.01, 8192)
+    st = h.stats()
+    assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
+    assert_parity(got, ref, "ties")
+    # exact ties: a constant-envelope signal with NO noise at all
+    k = np.random.default_rng(1).integers(0, 4, 2000)
+    x = np.repeat(np.exp(2j * np.pi * k / 4 + 0.2j), 8)
+    iq = np.empty(2 * x.size, np.float32)
+    iq[0::2] = x.real
+    iq[1::2] = x.imag
+    ref = oracle_run(oracle_mod, iq, props)
+    h2 = _handle()
+    h2.configure(0, [props])
+    got = run_gpu(h2, 0, iq, 0.01)
+    assert h2.stats()["channels_exact_timing"] == 1
+    assert_parity(got, ref, "exact ties")
+    h.close(); h2.close()
+
+
+def test_random_configuration_sweep(oracle_mod):
+    """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
+    and ragged packetisation, three calls each, every stream against the oracle: a broad net for
+    anything configuration- or lane-dependent (register allocation differs per instantiation)."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    rng = random.Random(2024)
+    n_ch = 256
+    props, iqs, cuts = [], [], []
+    for c in range(n_ch):
+        S = rng.choice([2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7])
+        A = rng.choice([1, 2, 17, 25, 64, 100, 100, 128, 129, 200, 256, 300, 400])
+        M = rng.choice([2, 4, 8])
+        n = rng.choice([1, 2, 10, 50, 50, 200, 384, 400])
+        p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.2))
+        props.append(p)
+        N = S * rng.choice([300, 700, 1500])
+        iqs.append(synth_channel(5000 + c, M, S, N, sigma=rng.choice([0.01, 0.01, 0.05, 0.2])))
+        cuts.append([0] + sorted(rng.sample(range(1, N), 2)) + [N])
+    h = _handle(n_ch, max_window_samples=16 * 400 + 64)
+    h.configure(0, props)
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
+    for k in range(3):
+        pk = [dict(data=iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], xdelta=0.01, sriChanged=(k == 0)) for c in range(n_ch)]
+        res = h.process_host(0, pk)
+        for c in range(n_ch):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    n_bitdiff = 0
+    for c in range(n_ch):
+        o = oracle_mod.OracleComponent()
+        for kk, v in props[c].items():
+            setattr(o, kk, v)
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(3):
+            r = o.service(iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        g = {k: np.concatenate(v) for k, v in got[c].items()}
+        r = {k: np.concatenate(v) for k, v in ref.items()}
+        assert np.array_equal(g["index"], r["index"]), (c, props[c])
+        assert g["bits"].size == r["bits"].size
+        n_bitdiff += int((g["bits"] != r["bits"]).sum())
+        for key in ("soft", "phase"):
+            a, b = g[key].astype(np.float64), r[key].astype(np.float64)
+            fin = np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), fin), (c, props[c], key)
+            if fin.any():
+                err = np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
+                assert err <= TOL, (c, props[c], key, err)
+    assert n_bitdiff == 0
+    h.close()
+
+
 def test_exactness_guard_hands_over(oracle_mod):
     """A burst 2^30 stronger than the noise around it breaks the exactness of the energy sums
     (quirk Q8): the wave-scan kernel must refuse and the reference-order kernel must match the

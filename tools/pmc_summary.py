@@ -15,4 +15,5 @@ for d in sys.argv[1:]:
         for k, cs in acc.items():
             print(f, k)
             for c, v in cs.items():
-                print("   %-24s n=%d mean=%.6g min=%.6g max=%.6g" % (c, len(v), sum(v) / len(v), min(v), max(v)))
+                vs = sorted(v)
+                print("   %-24s n=%d median=%.6g mean=%.6g min=%.6g max=%.6g" % (c, len(v), vs[len(vs) // 2], sum(v) / len(v), min(v), max(v)))
