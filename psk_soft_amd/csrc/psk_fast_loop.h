@@ -717,8 +717,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             cy.ySum = read_lane(ys, lane_last);
             cy.xySum = read_lane(xys, lane_last);
             cy.est = read_lane(e_, lane_last);
-            cy.last_re = read_lane(sre, lane_last);
-            cy.last_im = read_lane(sim, lane_last);
+            if (p.diff) {  // `last` only moves while differentialDecoding is on (cpp/psk_soft.cpp:486-491)
+                cy.last_re = read_lane(sre, lane_last);
+                cy.last_im = read_lane(sim, lane_last);
+            }
             const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
             if (pts_last > 1) {  // calculateDenominator ran for the window size reached (cpp/psk_soft.cpp:81-83)
                 cy.den = den_last;

@@ -321,3 +321,97 @@ def test_state_roundtrip(oracle_mod):
     for k in ("soft", "bits", "phase", "index"):
         assert np.array_equal(ga[k], gb[k]), k
     a.close(); b.close()
+
+
+def _replay(oracle_mod, h, script):
+    """script: list of ('set', name, value) / ('push', iq, kwargs).  Applies it to the oracle and
+    to channel 0 of handle h, comparing every call's four streams and SRI side channel."""
+    o = oracle_mod.OracleComponent()
+    n_call = 0
+    for step in script:
+        if step[0] == "set":
+            setattr(o, step[1], step[2])
+            h.configure(0, [{step[1]: step[2]}])
+            continue
+        iq, kw = step[1], step[2]
+        r = o.service(iq, kw.get("xdelta", 0.01), mode=kw.get("mode", 1), sriChanged=kw.get("sriChanged", False),
+                      inputQueueFlushed=kw.get("inputQueueFlushed", False))
+        g = h.process_host(0, [dict(data=iq, xdelta=kw.get("xdelta", 0.01), mode=kw.get("mode", 1),
+                                    sriChanged=kw.get("sriChanged", False), inputQueueFlushed=kw.get("inputQueueFlushed", False))])[0]
+        ctx = "call %d" % n_call
+        assert g["sri_pushed"] == r.sri_pushed and g["n_warn"] == r.n_warn, ctx
+        if r.sri_pushed:
+            assert g["sri_soft_xdelta"] == r.sri_soft_xdelta, ctx
+            assert g["sri_bits_xdelta"] == r.sri_bits_xdelta or (np.isnan(g["sri_bits_xdelta"]) and np.isnan(r.sri_bits_xdelta)), ctx
+        assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), ctx)
+        n_call += 1
+
+
+def test_property_changes_mid_stream(oracle_mod):
+    """samplesPerBaud / numAvg / constelationSize / phaseAvg / differentialDecoding /
+    resetState changed between packets, queue flush, xdelta change, an unsupported constellation
+    (no bits, one warning per symbol), numAvg shrinking below the filled window (the reference
+    then stalls: nothing more comes out until the window can fill again)."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq8 = synth_channel(31, 4, 8, 40000)
+    iq10 = synth_channel(32, 8, 10, 30000)
+    pos8 = [0]
+
+    def take8(n):
+        a = pos8[0]
+        pos8[0] += n
+        return iq8[2 * a : 2 * (a + n)]
+
+    script = [
+        ("set", "samplesPerBaud", 8), ("set", "constelationSize", 4), ("set", "numAvg", 100),
+        ("push", take8(3000), dict(sriChanged=True)),
+        ("set", "phaseAvg", 20), ("push", take8(2000), {}),
+        ("set", "phaseAvg", 120), ("push", take8(2000), {}),
+        ("set", "constelationSize", 8), ("push", take8(2500), {}),
+        ("set", "constelationSize", 16), ("push", take8(1000), {}),      # unsupported: no bits, warnings
+        ("set", "constelationSize", 2), ("set", "differentialDecoding", 1), ("push", take8(2000), {}),
+        ("set", "differentialDecoding", 0), ("set", "numAvg", 40), ("push", take8(1500), {}),   # shrink -> stall
+        ("push", take8(1000), {}),
+        ("set", "numAvg", 150), ("push", take8(3000), {}),                 # window can fill again
+        ("set", "resetState", 1), ("push", take8(2000), {}),
+        ("push", take8(1500), dict(inputQueueFlushed=True)),
+        ("push", take8(1500), dict(xdelta=0.5, sriChanged=True)),          # new sample rate: fit history cleared
+        ("push", take8(1000), dict(xdelta=1.0, sriChanged=True)),          # xdelta == 1.0: the Q3 comparison
+        ("push", take8(1000), dict(xdelta=1.0)),
+        ("set", "samplesPerBaud", 10), ("set", "constelationSize", 8), ("set", "numAvg", 60),
+        ("push", iq10[: 2 * 9000], {}),
+        ("set", "samplesPerBaud", 7), ("push", iq10[2 * 9000 : 2 * 14000], {}),   # no wave-scan instantiation
+        ("set", "samplesPerBaud", 1), ("push", iq10[2 * 14000 : 2 * 14500], {}),  # S == 1: nothing out (Q11)
+        ("set", "numAvg", 0), ("push", iq10[2 * 14500 : 2 * 15000], {}),
+        ("set", "resetState", 1), ("push", iq10[2 * 15000 : 2 * 15600], {}),      # S == 1, numAvg == 0: a symbol per sample
+        ("push", iq10[2 * 15600 : 2 * 16000], {}),
+        ("set", "samplesPerBaud", 10), ("set", "numAvg", 30), ("push", iq10[2 * 16000 : 2 * 22000], {}),
+    ]
+    h = _handle(max_window_samples=4096, max_phase_avg=256)
+    _replay(oracle_mod, h, script)
+    h.close()
+
+
+def test_call_longer_than_resync_count(oracle_mod):
+    """More than 1048576 symbols in ONE call: the reference resyncs symbolEnergy and the fit sums
+    in mid-loop (cpp/psk_soft.cpp:51-52, 582-583); such calls go to the reference-order kernel."""
+    n_sym = 1048576 + 3000
+    S = 2
+    rng = np.random.default_rng(9)
+    k = rng.integers(0, 2, n_sym + 10)
+    amp = np.tile(np.float32([1.0, 0.6]), n_sym + 10)
+    ph = np.repeat(np.pi * k + 0.4, S) + 2e-5 * np.arange((n_sym + 10) * S)
+    x = amp * np.exp(1j * ph) + 0.01 * (rng.standard_normal(ph.size) + 1j * rng.standard_normal(ph.size))
+    iq = np.empty(2 * x.size, np.float32)
+    iq[0::2] = x.real
+    iq[1::2] = x.imag
+    props = dict(samplesPerBaud=S, constelationSize=2, numAvg=10, phaseAvg=20)
+    ref = oracle_run(oracle_mod, iq, props)
+    assert ref["phase"].size > 1048576
+    h = _handle(max_packet_complex=iq.size // 2)
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01)
+    assert h.stats()["channels_sequential"] == 1
+    assert_parity(got, ref, "long call")
+    h.close()
