@@ -108,16 +108,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; PSK_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
+    backend = os.environ.get("PSK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     C, N, S, M = a.channels, a.nsamp, a.S, a.M
     bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
-    h = pl.Handle(C, device=local_rank, max_window_samples=max(16384, S * a.numAvg), max_phase_avg=max(512, a.phaseAvg))
+    h = pl.Handle(C, device=dev_index, max_window_samples=max(16384, S * a.numAvg), max_phase_avg=max(512, a.phaseAvg))
     h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)
 
     # synthetic section-8(d) workload, generated in HBM; every rank draws its own channels
@@ -168,7 +175,7 @@ def main():
     if world > 1:
         from psk_soft_amd.distributed import max_over_ranks
 
-        elapsed = max_over_ranks(elapsed, dist, dev)
+        elapsed = max_over_ranks(elapsed, dist, red_dev)
     # device time of one launch set (plan upload + wave-scan kernel + reference-order kernel),
     # HIP events on the stream the kernels run on
     dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)

@@ -33,12 +33,6 @@
 
 namespace psk {
 
-#ifndef PSK_REFUSE_EARLY_EXIT
-#define PSK_REFUSE_EARLY_EXIT 1
-#endif
-#ifndef PSK_PARK
-#define PSK_PARK 1
-#endif
 constexpr int kR = 2;           // symbols per lane per block
 constexpr int kB = kWave * kR;  // symbols per block
 constexpr int kMaxUnwrapPasses = 160;
@@ -162,30 +156,49 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
 template <int S>
 PSK_DEV void park_block(float *park, int lane, const BlockKeep<S> &b)
 {
+    // 16-byte pieces, [piece][lane]: conflict-free ds_write_b128 / ds_read_b128
+    constexpr int NF = kR * (S + 3);
+    float v[(NF + 3) / 4 * 4];
     int f = 0;
 #pragma unroll
     for (int r = 0; r < kR; r++) {
 #pragma unroll
-        for (int k = 0; k < S; k++) park[(f++) * kWave + lane] = b.e[r][k];
-        park[(f++) * kWave + lane] = b.pk[r].x;
-        park[(f++) * kWave + lane] = b.pk[r].y;
-        park[(f++) * kWave + lane] = __int_as_float(b.kp[r]);
+        for (int k = 0; k < S; k++) v[f++] = b.e[r][k];
+        v[f++] = b.pk[r].x;
+        v[f++] = b.pk[r].y;
+        v[f++] = __int_as_float(b.kp[r]);
     }
+#pragma unroll
+    for (; f < (NF + 3) / 4 * 4; f++) v[f] = 0.0f;
+    float4 *p4 = reinterpret_cast<float4 *>(park);
+#pragma unroll
+    for (int q = 0; q < (NF + 3) / 4; q++) p4[q * kWave + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 template <int S>
 PSK_DEV void unpark_block(const float *park, int lane, BlockKeep<S> &b)
 {
+    constexpr int NF = kR * (S + 3);
+    float v[(NF + 3) / 4 * 4];
+    const float4 *p4 = reinterpret_cast<const float4 *>(park);
+#pragma unroll
+    for (int q = 0; q < (NF + 3) / 4; q++) {
+        float4 t = p4[q * kWave + lane];
+        v[4 * q] = t.x;
+        v[4 * q + 1] = t.y;
+        v[4 * q + 2] = t.z;
+        v[4 * q + 3] = t.w;
+    }
     int f = 0;
 #pragma unroll
     for (int r = 0; r < kR; r++) {
 #pragma unroll
-        for (int k = 0; k < S; k++) b.e[r][k] = park[(f++) * kWave + lane];
-        b.pk[r].x = park[(f++) * kWave + lane];
-        b.pk[r].y = park[(f++) * kWave + lane];
-        b.kp[r] = __float_as_int(park[(f++) * kWave + lane]);
+        for (int k = 0; k < S; k++) b.e[r][k] = v[f++];
+        b.pk[r].x = v[f++];
+        b.pk[r].y = v[f++];
+        b.kp[r] = __float_as_int(v[f++]);
     }
 }
-constexpr int park_floats(int S) { return kR * (S + 3) * kWave; }
+constexpr int park_floats(int S) { return (kR * (S + 3) + 3) / 4 * 4 * kWave; }
 
 // value of `field` in the block `back` blocks back in time (0 = cur, j >= 1 = hist[j-1]); back is
 // wave-uniform and at most H
@@ -427,13 +440,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     const int n_blocks = (n_out + kB - 1) / kB;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
-    if constexpr (H == 1 && PSK_PARK)
+    if constexpr (H == 1)
         park_block<S>(park, lane, hist[0]);
 
     for (int c = 0; c < n_blocks; c++) {
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
-        if constexpr (H == 1 && PSK_PARK)
+        if constexpr (H == 1)
             unpark_block<S>(park, lane, hist[0]);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
@@ -531,14 +544,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             wmax_prev = wmax;
             since_refresh++;
             // a near-tie (or a non-finite energy) anywhere: the call goes to the exact kernel
-#if PSK_REFUSE_EARLY_EXIT
             if (!__all(ok0 && ok1)) {
                 cy.refuse = true;
                 return;
             }
-#else
-            cy.refuse = cy.refuse || !(ok0 && ok1);  // (nothing is committed; the wave just runs on)
-#endif
         } else {
             // ---- exact pass: float-valued addends summed in double ----
             double bestW[kR] = {0.0, 0.0};
@@ -596,7 +605,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 #pragma unroll
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;
-        if constexpr (H == 1 && PSK_PARK)
+        if constexpr (H == 1)
             park_block<S>(park, lane, cur);  // not needed again before the next block
 
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================

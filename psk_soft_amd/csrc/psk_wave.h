@@ -135,10 +135,13 @@ PSK_DEV unsigned wave_min_u32(unsigned v)
     }
     return v;
 }
-// orders LDS traffic of this wave: a later ds_read sees an earlier ds_write of another lane
+// Orders this wave's LDS traffic: a later ds_read sees an earlier ds_write of another lane.  The
+// LDS executes one wave's instructions in issue order, so all that is needed is that the COMPILER
+// keeps the order (a wavefront-scope fence would also wait for every outstanding global load and
+// store -- vmcnt(0) -- which exposes store latency inside the fit loop).
 PSK_DEV void wave_lds_fence()
 {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
