@@ -253,14 +253,14 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             xavg_l[r] = xavg_s;
         }
     }
-    // speculate numWraps by consecutive differences; position 0 is exact (carried estimate)
+    // speculate numWraps by consecutive differences (position 0: against the carried estimate)
     int w[kR];
     {
         // (a guess only: float arithmetic is enough; every count is verified below)
         const float rf0 = (float)rawd[0], rf1 = (float)rawd[1];
-        const float rprev = wave_up1(rf1, rf1);
         const float inv2pi = 0.15915494f;
-        int dl0 = (lane == 0) ? (int)unwrap_count(cy.est, rawd[0]) : (int)__builtin_rintf((rprev - rf0) * inv2pi);
+        const float rprev = wave_up1(rf1, cy.est);  // lane 0: the carried estimate
+        int dl0 = (int)__builtin_rintf((rprev - rf0) * inv2pi);
         int dl1 = (int)__builtin_rintf((rf0 - rf1) * inv2pi);
         int incl = wave_scan_i32(dl0 + dl1);
         w[1] = incl;
@@ -511,35 +511,54 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         int bestK[kR] = {0, 0};
         if constexpr (!EXACT) {
             // ---- screening pass in float ----
-            float b1[kR], b2[kR];  // best and second-best window sum
+            // All S scans run interleaved.  The argmax works on the float bit patterns as
+            // integers (the sums are >= 0 up to their error bound; the sign bit is dropped): the
+            // low IB bits carry the phase index, so one max chain yields best sum AND index, and
+            // a median-of-three chain the runner-up.  Dropping the sign and overwriting IB low
+            // bits moves a value by at most 2*E + 2^IB ulp; the acceptance threshold below
+            // absorbs that.  A NaN anywhere has the largest pattern and fails the test.
+            constexpr int IB = S <= 2 ? 1 : S <= 4 ? 2 : S <= 8 ? 3 : 4;
+            constexpr int IMASK = (1 << IB) - 1;
+            float inc[S], d1v[S];
 #pragma unroll
             for (int k = 0; k < S; k++) {
-                float d0 = cur.e[0][k] - e_old[0][k];
-                float d1 = cur.e[1][k] - e_old[1][k];
-                float incl = wave_scan_f32(d0 + d1);
-                float W1 = Wf[k] + incl;
-                float W0 = W1 - d1;
+                const float d0 = cur.e[0][k] - e_old[0][k];
+                d1v[k] = cur.e[1][k] - e_old[1][k];
+                inc[k] = d0 + d1v[k];
+            }
+            wave_scan_f32_multi<S>(inc);
+            int m1[kR], m2[kR];
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                const float W1 = Wf[k] + inc[k];
+                const float W0 = W1 - d1v[k];
                 Wf[k] = read_lane(W1, 63);
+                const int p0 = (__float_as_int(W0) & (0x7FFFFFFF & ~IMASK)) | (IMASK - k);
+                const int p1 = (__float_as_int(W1) & (0x7FFFFFFF & ~IMASK)) | (IMASK - k);
                 if (k == 0) {
-                    b1[0] = W0;
-                    b1[1] = W1;
-                    b2[0] = -__builtin_inff();
-                    b2[1] = -__builtin_inff();
+                    m1[0] = p0;
+                    m1[1] = p1;
+                } else if (k == 1) {
+                    m2[0] = p0 < m1[0] ? p0 : m1[0];
+                    m2[1] = p1 < m1[1] ? p1 : m1[1];
+                    m1[0] = p0 > m1[0] ? p0 : m1[0];
+                    m1[1] = p1 > m1[1] ? p1 : m1[1];
                 } else {
-                    const bool g0 = W0 > b1[0], g1 = W1 > b1[1];
-                    b2[0] = g0 ? b1[0] : __builtin_fmaxf(b2[0], W0);
-                    b2[1] = g1 ? b1[1] : __builtin_fmaxf(b2[1], W1);
-                    b1[0] = g0 ? W0 : b1[0];
-                    b1[1] = g1 ? W1 : b1[1];
-                    bestK[0] = g0 ? k : bestK[0];
-                    bestK[1] = g1 ? k : bestK[1];
+                    m2[0] = med3_i32(m1[0], m2[0], p0);
+                    m2[1] = med3_i32(m1[1], m2[1], p1);
+                    m1[0] = p0 > m1[0] ? p0 : m1[0];
+                    m1[1] = p1 > m1[1] ? p1 : m1[1];
                 }
             }
-            const float wmax = __builtin_fmaxf(wave_max_f32(__builtin_fmaxf(b1[0], b1[1])), wmax_prev);
+            bestK[0] = IMASK - (m1[0] & IMASK);
+            bestK[1] = IMASK - (m1[1] & IMASK);
+            const int mm = m1[0] > m1[1] ? m1[0] : m1[1];
+            const float wmax = __builtin_fmaxf(wave_max_f32(__int_as_float(mm)), wmax_prev);
             const float e_blk = c_blk * wmax;
-            const float thr = 2.0f * (err_c + e_blk);
+            const float thr = 6.0f * (err_c + e_blk) + (float)(4 << IB) * kU * wmax;
             // (NaN / inf anywhere makes the comparison false)
-            const bool ok0 = !valid[0] || ((b1[0] - b2[0]) > thr), ok1 = !valid[1] || ((b1[1] - b2[1]) > thr);
+            const bool ok0 = !valid[0] || ((__int_as_float(m1[0]) - __int_as_float(m2[0])) > thr);
+            const bool ok1 = !valid[1] || ((__int_as_float(m1[1]) - __int_as_float(m2[1])) > thr);
             err_c += e_blk;
             wmax_prev = wmax;
             since_refresh++;

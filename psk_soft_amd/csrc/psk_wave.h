@@ -59,33 +59,68 @@ PSK_DEV double wave_scan_f64(double v)
     v += dpp_zero_f64<0x143, 0xC>(v);
     return v;
 }
-// float versions: the adds / maxes fold their DPP source (one instruction a step)
-template <int CTRL>
-PSK_DEV float dpp_shr0_f32(float v)
-{
-    return __int_as_float(dpp_shr0<CTRL>(__float_as_int(v)));
-}
+// float versions, one instruction a step: the DPP source is folded into the add / max, and for
+// the two cross-row steps the rows masked off simply keep their value (the compiler's own
+// lowering needs a zeroed temporary and a separate add there).  Written as asm because that
+// folding is not reachable from the builtins; the s_nop's are the two wait states a DPP read
+// needs after a VALU write of the same register.
+#define PSK_DPP_STEP(op, ctl) op " %0, %0, %0 " ctl
+#define PSK_DPP_ROW1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define PSK_DPP_ROW2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define PSK_DPP_ROW4 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define PSK_DPP_ROW8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define PSK_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define PSK_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
 PSK_DEV float wave_scan_f32(float v)
 {
-    v += dpp_shr0_f32<0x111>(v);
-    v += dpp_shr0_f32<0x112>(v);
-    v += dpp_shr0_f32<0x114>(v);
-    v += dpp_shr0_f32<0x118>(v);
-    v += __int_as_float(dpp_zero<0x142, 0xA>(__float_as_int(v)));
-    v += __int_as_float(dpp_zero<0x143, 0xC>(__float_as_int(v)));
+    asm volatile("s_nop 1\n\t" PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW1) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW2) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW4) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW8) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_BC15) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_BC31)
+                 : "+v"(v));
     return v;
+}
+// N independent scans, interleaved step by step: with N >= 3 the other chains fill the wait states
+template <int N>
+PSK_DEV void wave_scan_f32_multi(float (&v)[N])
+{
+#define PSK_SCAN_LEVEL(ctl, first)                                                            \
+    _Pragma("unroll") for (int i = 0; i < N; i++)                                             \
+    {                                                                                         \
+        if (first || N < 3) /* (the compiler may place the producer of v[i] right before) */  \
+            asm volatile("s_nop 1\n\t" PSK_DPP_STEP("v_add_f32_dpp", ctl) : "+v"(v[i]));      \
+        else                                                                                  \
+            asm volatile(PSK_DPP_STEP("v_add_f32_dpp", ctl) : "+v"(v[i]));                    \
+    }
+    PSK_SCAN_LEVEL(PSK_DPP_ROW1, true)
+    PSK_SCAN_LEVEL(PSK_DPP_ROW2, false)
+    PSK_SCAN_LEVEL(PSK_DPP_ROW4, false)
+    PSK_SCAN_LEVEL(PSK_DPP_ROW8, false)
+    PSK_SCAN_LEVEL(PSK_DPP_BC15, false)
+    PSK_SCAN_LEVEL(PSK_DPP_BC31, false)
+#undef PSK_SCAN_LEVEL
 }
 // max over the wave of non-negative values: lanes without a source read 0, so the running
 // maximum of lane 63 is the wave maximum
 PSK_DEV float wave_max_f32(float v)
 {
-    v = __builtin_fmaxf(v, dpp_shr0_f32<0x111>(v));
-    v = __builtin_fmaxf(v, dpp_shr0_f32<0x112>(v));
-    v = __builtin_fmaxf(v, dpp_shr0_f32<0x114>(v));
-    v = __builtin_fmaxf(v, dpp_shr0_f32<0x118>(v));
-    v = __builtin_fmaxf(v, __int_as_float(dpp_zero<0x142, 0xA>(__float_as_int(v))));
-    v = __builtin_fmaxf(v, __int_as_float(dpp_zero<0x143, 0xC>(__float_as_int(v))));
+    asm volatile("s_nop 1\n\t" PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW1) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW2) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW4) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW8) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_BC15) "\n\ts_nop 1\n\t"
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_BC31)
+                 : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// median of three signed integers (v_med3_i32)
+PSK_DEV int med3_i32(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 PSK_DEV int wave_scan_i32(int v)
 {
