@@ -110,6 +110,7 @@ PSK_DEV cf32 cpow_uint(cf32 x, unsigned n)
 // complex<float> divide = libgcc __divsc3 as a g++-linked binary resolves it in the oracle
 // image (GCC 12 libgcc_s: quotient formed in double, one rounding per part, then the
 // Annex G recovery) -- cpp/psk_soft.cpp:488, differential decoding only (quirk Q10).
+template <bool RECOVER>
 PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
 {
     float a = n.re, b = n.im, c = dn.re, d = dn.im;
@@ -117,7 +118,7 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
     double denom = (cc * cc) + (dd * dd);
     float x = (float)(((aa * cc) + (bb * dd)) / denom);
     float y = (float)(((bb * cc) - (aa * dd)) / denom);
-    if (is_nan(x) && is_nan(y)) {
+    if (RECOVER && is_nan(x) && is_nan(y)) {
         if (c == 0.0f && d == 0.0f && (!is_nan(a) || !is_nan(b))) {
             x = __builtin_copysignf(__builtin_inff(), c) * a;
             y = __builtin_copysignf(__builtin_inff(), c) * b;
@@ -141,21 +142,36 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
 
 // atan2f / sincosf for a whole wave: the straight-line form, and the general routine only if
 // some lane holds a special argument (wave-uniform branch, practically never taken)
-PSK_DEV float atan2f_wave(float y, float x)
+//
+// LEAN = true leaves the general routine out of the instruction stream altogether: a special
+// argument is only reported (special |= ...) and the caller hands the whole call to the next
+// kernel tier, which has the general routine.
+template <bool LEAN>
+PSK_DEV float atan2f_wave(float y, float x, bool &special)
 {
     bool sp;
     float r = lm_atan2f_ordinary(y, x, &sp);
-    if (__any(sp)) {
+    if (LEAN) {
+        special = special || sp;
+    } else if (__any(sp)) {
         if (sp)
             r = lm_atan2f(y, x);
     }
     return r;
 }
-PSK_DEV void sincosf_wave(float t, float *sn, float *cs)
+PSK_DEV float atan2f_wave(float y, float x)
+{
+    bool unused = false;
+    return atan2f_wave<false>(y, x, unused);
+}
+template <bool LEAN>
+PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special)
 {
     bool sp;
     lm_sincosf_ordinary(t, sn, cs, &sp);
-    if (__any(sp)) {
+    if (LEAN) {
+        special = special || sp;
+    } else if (__any(sp)) {
         if (sp)
             lm_sincosf(t, sn, cs);
     }
@@ -208,20 +224,51 @@ PSK_DEV float fit_value(double ySum, double xySum, float xdelta, unsigned pts, f
     return mxv + b;
 }
 
-// calculateFit with the two divisors' reciprocals precomputed (steady state: they are
-// wave-uniform): rden = 1.0/(double)denominator, rpts = 1.0/(double)pts
-PSK_DEV float fit_value_known(double ySum, double xySum, float xdelta, unsigned pts, float denominator, float xAvg,
-                              double rden, double rpts, float &m_out, float &b_out)
+// A wave-uniform value, told to the compiler as such: it then lives in scalar registers instead
+// of occupying a vector register in every lane (v_readfirstlane).
+// (The builtin alone is folded away when the operand is already known to be uniform, which
+// leaves the value in the vector register its floating-point producer wrote; or-ing in a zero
+// the compiler cannot see through keeps it.)
+PSK_DEV int uni(int v)
 {
-    unsigned pts_m_1 = pts - 1;
-    float half_span = xdelta * (float)pts_m_1 / 2;
-    float m = (float)lm_div_known(xySum - (double)half_span * ySum, (double)denominator, rden);
-    float mx = m * xAvg;
-    float b = (float)(lm_div_known(ySum, (double)pts, rpts) - (double)mx);
-    float xVal = xdelta * (float)pts_m_1;
-    float mxv = m * xVal;
-    m_out = m;
-    b_out = b;
+    int z;
+    asm("v_mov_b32 %0, 0" : "=v"(z));
+    return __builtin_amdgcn_readfirstlane(v | z);
+}
+PSK_DEV float uni(float v) { return __int_as_float(uni(__float_as_int(v))); }
+PSK_DEV double uni(double v) { return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v))); }
+
+// calculateFit in the steady state (the window holds phaseAvg points): every operand that depends
+// only on (xdelta, phaseAvg) is precomputed once per call, the two divisions become
+// multiplications by correctly rounded reciprocals (lm_div_known).  All members are wave-uniform.
+struct FitKnown {
+    float xd;        // LinearFit::xdelta
+    float sizef;     // (float)(yvals.size()) before the push, cpp/psk_soft.cpp:78
+    float xavg;      // xAvg
+    float xval;      // xdelta * (pts-1), the abscissa of the newest point
+    double half_span_d, den_d, rden, pts_d, rpts;
+};
+PSK_DEV FitKnown fit_known(float xdelta, unsigned pts, float denominator, float xAvg)
+{
+    FitKnown k;
+    const unsigned pts_m_1 = pts - 1;
+    k.xd = uni(xdelta);
+    k.sizef = uni((float)pts_m_1);
+    k.xavg = uni(xAvg);
+    k.xval = uni(xdelta * (float)pts_m_1);
+    k.half_span_d = uni((double)(xdelta * (float)pts_m_1 / 2));
+    k.den_d = uni((double)denominator);
+    k.rden = uni(1.0 / (double)denominator);
+    k.pts_d = uni((double)pts);
+    k.rpts = uni(1.0 / (double)pts);
+    return k;
+}
+PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k)
+{
+    float m = (float)lm_div_known(xySum - k.half_span_d * ySum, k.den_d, k.rden);
+    float mx = m * k.xavg;
+    float b = (float)(lm_div_known(ySum, k.pts_d, k.rpts) - (double)mx);
+    float mxv = m * k.xval;
     return mxv + b;
 }
 
@@ -239,9 +286,10 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 }
 
 // 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
-PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
+template <bool LEAN>
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special)
 {
-    float theta = atan2f_wave(c_im, c_re);
+    float theta = atan2f_wave<LEAN>(c_im, c_re, special);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)
         softsym = softsym + 8.0f;
@@ -252,6 +300,12 @@ PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
     else
         asInt = (int)r;
     return (unsigned short)(unsigned)asInt;
+}
+
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
+{
+    bool unused = false;
+    return slice_8psk<false>(c_re, c_im, unused);
 }
 
 }  // namespace psk

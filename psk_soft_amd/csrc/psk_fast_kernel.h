@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
 {
     __shared__ float yring[kYRing];
-    __shared__ __attribute__((aligned(16))) float park[(SV != 0 && HV == 1) ? park_floats(SV == 0 ? 2 : SV) : 4];
+    __shared__ __attribute__((aligned(16))) float ering[(SV != 0 && HV == 1) ? ering_floats(SV == 0 ? 2 : SV) : 4];
     const int lane = threadIdx.x & 63;
     const ChanPlan &p = plans[blockIdx.x];
     if (p.mode != PLAN_FAST)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
 
     // ---- the symbol loop ----
     if constexpr (SV != 0)
-        fast_main_loop<SV, HV, EXACT>(p, X, yring, park, cy);
+        fast_main_loop<SV, HV, EXACT>(p, X, yring, ering, cy);
 
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
     //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53 ----

@@ -31,6 +31,12 @@
 
 #include "psk_wave.h"
 
+// keeps the instruction scheduler from interleaving two stages of the block loop (which would
+// overlap their register demands); no instruction is emitted
+#ifndef PSK_STAGE_FENCE
+#define PSK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace psk {
 
 constexpr int kR = 2;           // symbols per lane per block
@@ -151,54 +157,40 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
     }
 }
 
-// Parking of the kept block in LDS while the phase part of the loop runs (numAvg <= 128 only:
-// frees its 6 + 2S registers where the register budget is tightest).  Layout [field][lane].
+// numAvg <= 128 (H == 1): the energies of the last 256 symbol positions live in an LDS ring,
+// ering[k][position & 255], instead of registers.  A block writes its 128 positions (one 8-byte
+// store per phase: a lane's two positions are adjacent) and reads back the energies that sat
+// numAvg positions earlier -- part of them written a moment ago by other lanes, the rest by the
+// previous block.  No cross-lane permutes, no selects, and 2*S fewer live registers.
+constexpr int kERing = 2 * kB;
 template <int S>
-PSK_DEV void park_block(float *park, int lane, const BlockKeep<S> &b)
+PSK_DEV void ering_put(float *ering, int base, int lane, const float (&e)[kR][S])
 {
-    // 16-byte pieces, [piece][lane]: conflict-free ds_write_b128 / ds_read_b128
-    constexpr int NF = kR * (S + 3);
-    float v[(NF + 3) / 4 * 4];
-    int f = 0;
 #pragma unroll
-    for (int r = 0; r < kR; r++) {
-#pragma unroll
-        for (int k = 0; k < S; k++) v[f++] = b.e[r][k];
-        v[f++] = b.pk[r].x;
-        v[f++] = b.pk[r].y;
-        v[f++] = __int_as_float(b.kp[r]);
-    }
-#pragma unroll
-    for (; f < (NF + 3) / 4 * 4; f++) v[f] = 0.0f;
-    float4 *p4 = reinterpret_cast<float4 *>(park);
-#pragma unroll
-    for (int q = 0; q < (NF + 3) / 4; q++) p4[q * kWave + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    for (int k = 0; k < S; k++)
+        *reinterpret_cast<float2 *>(ering + k * kERing + base + 2 * lane) = make_float2(e[0][k], e[1][k]);
 }
 template <int S>
-PSK_DEV void unpark_block(const float *park, int lane, BlockKeep<S> &b)
+PSK_DEV void ering_get(const float *ering, int base, int lane, uint32_t D, float (&e)[kR][S])
 {
-    constexpr int NF = kR * (S + 3);
-    float v[(NF + 3) / 4 * 4];
-    const float4 *p4 = reinterpret_cast<const float4 *>(park);
+    const int i0 = (base + 2 * lane - (int)D) & (kERing - 1);
+    if ((D & 1u) == 0) {  // the pair stays 8-byte aligned (and never straddles the wrap)
 #pragma unroll
-    for (int q = 0; q < (NF + 3) / 4; q++) {
-        float4 t = p4[q * kWave + lane];
-        v[4 * q] = t.x;
-        v[4 * q + 1] = t.y;
-        v[4 * q + 2] = t.z;
-        v[4 * q + 3] = t.w;
-    }
-    int f = 0;
+        for (int k = 0; k < S; k++) {
+            const float2 t = *reinterpret_cast<const float2 *>(ering + k * kERing + i0);
+            e[0][k] = t.x;
+            e[1][k] = t.y;
+        }
+    } else {
+        const int i1 = (i0 + 1) & (kERing - 1);
 #pragma unroll
-    for (int r = 0; r < kR; r++) {
-#pragma unroll
-        for (int k = 0; k < S; k++) b.e[r][k] = v[f++];
-        b.pk[r].x = v[f++];
-        b.pk[r].y = v[f++];
-        b.kp[r] = __float_as_int(v[f++]);
+        for (int k = 0; k < S; k++) {
+            e[0][k] = ering[k * kERing + i0];
+            e[1][k] = ering[k * kERing + i1];
+        }
     }
 }
-constexpr int park_floats(int S) { return (kR * (S + 3) + 3) / 4 * 4 * kWave; }
+constexpr int ering_floats(int S) { return S * kERing; }
 
 // value of `field` in the block `back` blocks back in time (0 = cur, j >= 1 = hist[j-1]); back is
 // wave-uniform and at most H
@@ -224,8 +216,8 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
 // Returns the number of extra passes; den_last / xavg_last = LinearFit::denominator / xAvg after
 // the block's last valid symbol.
 template <bool WARM>
-PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, double rden_s,
-                      double rpts_s, const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
+PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk,
+                      const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
                       float *yring, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
                       int lane_last, int r_last, float &den_last, float &xavg_last)
 {
@@ -247,7 +239,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
                 fit_denominator(xd, pts[r], den_l[r], xavg_l[r]);
         } else {
             steady[r] = true;
-            sizef[r] = (float)(n - 1);
+            sizef[r] = fk.sizef;
             pts[r] = n;
             den_l[r] = den_s;
             xavg_l[r] = xavg_s;
@@ -304,7 +296,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         for (int r = 0; r < kR; r++) {
             float m_, b_;
             if (!WARM) {  // steady state: both divisors are wave-uniform
-                est[r] = fit_value_known(ySum_l[r], xySum_l[r], xd, n, den_s, xavg_s, rden_s, rpts_s, m_, b_);
+                est[r] = fit_value_known(ySum_l[r], xySum_l[r], fk);
             } else if (pts[r] > 1) {
                 est[r] = fit_value(ySum_l[r], xySum_l[r], xd, pts[r], den_l[r], xavg_l[r], m_, b_);
             } else {  // :164-171, a single point: b = yvals.back()
@@ -359,8 +351,21 @@ PSK_DEV float window_end_f32(const BlockKeep<S> (&hist)[H], uint32_t A, int lane
     return read_lane(wave_scan_f32(acc), 63);
 }
 
+// the same for numAvg <= 128 from the LDS ring: the window is the positions >= kB - A of the block
+// at `base`
+PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int lane, int k)
+{
+    const float2 t = *reinterpret_cast<const float2 *>(ering + k * kERing + base + 2 * lane);
+    float acc = 0.0f;
+    if (2 * lane >= kB - (int)A)
+        acc += t.x;
+    if (2 * lane + 1 >= kB - (int)A)
+        acc += t.y;
+    return read_lane(wave_scan_f32(acc), 63);
+}
+
 template <int S, int H, bool EXACT>
-PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *park, FastCarry &cy)
+PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *ering, FastCarry &cy)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t A = p.A, M = p.M, n = p.lf_n;
@@ -398,7 +403,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 #pragma unroll
         for (int k = 0; k < S; k++) {
             Wc[k] = wave_sum_f64(acc[k]);
-            Wf[k] = (float)Wc[k];
+            Wf[k] = uni((float)Wc[k]);
         }
     }
     // error bound of the float shadow (screened path)
@@ -410,7 +415,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     // rounding-error budget of one screened block, relative to the largest window sum in play:
     // the local roundings of up to 2*(128/A+1) window-loads of energy pass through the scan, plus
     // the scan's own additions and the carry
-    const float c_blk = kU * (64.0f + 16.0f * ((float)kB / (float)A + 1.0f));
+    const float c_blk = uni(kU * (64.0f + 16.0f * ((float)kB / (float)A + 1.0f)));
     int since_refresh = 0;
 
     // cross-lane fetch parameters: energies leave the window A symbols after they entered it;
@@ -424,10 +429,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     float den_s = cy.den, xavg_s = cy.xavg;
     if (n > 1)
         fit_denominator(xd, n, den_s, xavg_s);
-    const double rden_s = 1.0 / (double)den_s, rpts_s = 1.0 / (double)n;
+    const FitKnown fk = fit_known(xd, n, den_s, xavg_s);
     // -est/M (cpp/psk_soft.cpp:494): for a power-of-two M the division is an exact scaling
     const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
-    const float inv_M = 1.0f / (float)(M ? M : 1);
+    const float inv_M = uni(1.0f / (float)(M ? M : 1));
 
     if constexpr (!EXACT) {
         // the screened kernel is specialised for the steady state: a call that starts with the fit
@@ -441,13 +446,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
     if constexpr (H == 1)
-        park_block<S>(park, lane, hist[0]);
+        ering_put<S>(ering, kB, lane, hist[0].e);  // block -1
 
     for (int c = 0; c < n_blocks; c++) {
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
-        if constexpr (H == 1)
-            unpark_block<S>(park, lane, hist[0]);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -474,17 +477,25 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         // energy of symbol i-1 for every phase (it entered the window A symbols before symbol
         // i+A-1 did): all cross-lane fetches issued back to back
         float e_old[kR][S];
+        if constexpr (H == 1) {
+            const int base = (c & 1) * kB;
+            ering_put<S>(ering, base, lane, cur.e);
+            wave_lds_fence();
+            ering_get<S>(ering, base, lane, A, e_old);
+        } else {
 #pragma unroll
-        for (int k = 0; k < S; k++) {
-            float nw[kR], od[kR];
+            for (int k = 0; k < S; k++) {
+                float nw[kR], od[kR];
 #pragma unroll
-            for (int rr = 0; rr < kR; rr++) {
-                nw[rr] = block_back<S, H>(uE, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
-                od[rr] = block_back<S, H>(uE + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                for (int rr = 0; rr < kR; rr++) {
+                    nw[rr] = block_back<S, H>(uE, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                    od[rr] = block_back<S, H>(uE + 1, cur, hist, [&](const BlockKeep<S> &b) { return b.e[rr][k]; });
+                }
+#pragma unroll
+                for (int r = 0; r < kR; r++) e_old[r][k] = rot_pull<float>(rotE, r, nw, od);
             }
-#pragma unroll
-            for (int r = 0; r < kR; r++) e_old[r][k] = rot_pull<float>(rotE, r, nw, od);
         }
+        PSK_STAGE_FENCE();
         // the sample kept A-1 symbols ago for the symbol now being output, and the index it was kept at
         float px[kR], py[kR];
         int pkk[kR];
@@ -508,6 +519,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             }
         }
 
+        PSK_STAGE_FENCE();
         int bestK[kR] = {0, 0};
         if constexpr (!EXACT) {
             // ---- screening pass in float ----
@@ -623,20 +635,27 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         // history for the next block
 #pragma unroll
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
-        hist[0] = cur;
-        if constexpr (H == 1)
-            park_block<S>(park, lane, cur);  // not needed again before the next block
+        hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
 
+        PSK_STAGE_FENCE();
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
+        // The screened kernel carries only the straight-line forms of atan2f / sincosf and of the
+        // complex multiply / divide; an argument that needs the general routine (zeros, NaN,
+        // x == 1, ...) makes it refuse the call, and the exact kernel -- which has them -- redoes it.
+        constexpr bool LEAN = !EXACT;
+        bool special = false;
         double rawd[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             cf32 pw = cpow_uint<false>(s[r], M);
             if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
                 cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-            rawd[r] = (double)atan2f_wave(pw.im, pw.re);
+            bool sp = false;
+            rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp);
+            special = special || (valid[r] && sp);
         }
 
+        PSK_STAGE_FENCE();
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
         const uint32_t q0 = cy.q;
         float y[kR], est[kR];
@@ -644,17 +663,18 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         float den_last = den_s, xavg_last = xavg_s;
         int pass;
         if (!EXACT || __builtin_expect(q0 >= n, 1)) {
-            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
-                                    xySum_l, lane_last, r_last, den_last, xavg_last);
+            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
+                                    lane_last, r_last, den_last, xavg_last);
         } else {  // (the screened kernel never gets here: it leaves warm-up calls to this one)
-            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, rden_s, rpts_s, valid, rawd, cy, yring, y, est, ySum_l,
-                                   xySum_l, lane_last, r_last, den_last, xavg_last);
+            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
+                                   lane_last, r_last, den_last, xavg_last);
         }
         if (pass > kMaxUnwrapPasses)
             cy.refuse = true;
         cy.stat_blocks += 1;
         cy.stat_extra += (uint32_t)pass;
 
+        PSK_STAGE_FENCE();
         // ================= de-rotation and hard decisions (reference cpp/psk_soft.cpp:484-566) =================
         cf32 corr[kR];
 #pragma unroll
@@ -669,20 +689,27 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 } else {
                     last = s[0];
                 }
-                smp = cdiv(s[r], last);
+                smp = cdiv<!LEAN>(s[r], last);
+                if (LEAN)  // __divsc3's recovery branch belongs to the next tier
+                    special = special || (valid[r] && is_nan(smp.re) && is_nan(smp.im));
             } else {
                 phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
             }
             if (M == 4)
                 phaseCorrection = (float)((double)phaseCorrection + kPi4);
             float sn, cs;
-            sincosf_wave(phaseCorrection, &sn, &cs);
+            bool sp = false;
+            sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp);
+            special = special || (valid[r] && sp);
             cf32 ph;
             ph.re = 1.0f * cs;
             ph.im = 1.0f * sn;
-            corr[r] = cmul<true>(smp, ph);
+            corr[r] = cmul<!LEAN>(smp, ph);
+            if (LEAN)  // (__mulsc3's recovery branch likewise)
+                special = special || (valid[r] && is_nan(corr[r].re) && is_nan(corr[r].im));
         }
 
+        PSK_STAGE_FENCE();
         // ---- four output streams, two symbols per lane ----
         if (valid[1]) {
             typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
@@ -706,7 +733,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 s4u v = {(short)(r0 ^ m0), (short)(!m0), (short)(r1 ^ m1), (short)(!m1)};
                 *reinterpret_cast<s4u *>(p.bits + 2 * i0) = v;
             } else if (p.bpb == 3) {
-                unsigned short a = slice_8psk(corr[0].re, corr[0].im), b = slice_8psk(corr[1].re, corr[1].im);
+                bool sp = false;
+                unsigned short a = slice_8psk<LEAN>(corr[0].re, corr[0].im, sp), b = slice_8psk<LEAN>(corr[1].re, corr[1].im, sp);
+                special = special || sp;
                 s2u v0 = {(short)(a & 1), (short)((a >> 1) & 1)};
                 s2u v1 = {(short)((a >> 2) & 1), (short)(b & 1)};
                 s2u v2 = {(short)((b >> 1) & 1), (short)((b >> 2) & 1)};
@@ -728,11 +757,18 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 p.bits[2 * i0] = (int16_t)(r0 ^ m0);
                 p.bits[2 * i0 + 1] = (int16_t)(!m0);
             } else if (p.bpb == 3) {
-                unsigned short a = slice_8psk(corr[0].re, corr[0].im);
+                bool sp = false;
+                unsigned short a = slice_8psk<LEAN>(corr[0].re, corr[0].im, sp);
+                special = special || sp;
                 p.bits[3 * i0] = (int16_t)(a & 1);
                 p.bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
                 p.bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
             }
+        }
+
+        if (LEAN && __any(special)) {
+            cy.refuse = true;
+            return;
         }
 
         // ---- carries into the next block: the last valid position of this one ----
@@ -764,7 +800,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 float wm = 0.0f;
 #pragma unroll
                 for (int k = 0; k < S; k++) {
-                    Wf[k] = window_end_f32<S, H>(hist, A, lane, k);
+                    if constexpr (H == 1)
+                        Wf[k] = window_end_ring_f32(ering, (c & 1) * kB, A, lane, k);
+                    else
+                        Wf[k] = window_end_f32<S, H>(hist, A, lane, k);
                     wm = __builtin_fmaxf(wm, Wf[k]);
                 }
                 wmax_prev = __builtin_fmaxf(wmax_prev, wm);

@@ -119,7 +119,7 @@ __device__ void seq_emit_symbol(SeqEmit &E, cf32 sample, int sampleIndex, bool h
         p.phase[i] = E.pe;
     float phaseCorrection = 0.0f;
     if (p.diff) {
-        cf32 decoded = cdiv(sample, E.last);
+        cf32 decoded = cdiv<true>(sample, E.last);
         E.last = sample;
         sample = decoded;
     } else {

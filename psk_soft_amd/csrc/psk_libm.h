@@ -243,8 +243,8 @@ PSK_HD void lm_sincosf(float y, float *sp, float *cp)
 
 // ---------------------------------------------------------------------------------
 // Straight-line forms for SIMD execution.  They return the same bits as lm_atan2f /
-// lm_sincosf for every "ordinary" argument and set *special for the rest (NaN, inf, zeros,
-// x == 1, extreme ratios, |theta| >= 120): the caller then takes the general routine above.
+// lm_sincosf for every "ordinary" argument and set *special for the rest (atan2f: an infinite or
+// NaN operand; sincosf: |theta| >= 120, inf, NaN): the caller then takes the general routine above.
 // tests/support/libm_pin.cpp checks fast == general wherever *special is false.
 // ---------------------------------------------------------------------------------
 PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
@@ -254,16 +254,15 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
                 aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
                 aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
-    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pi_o_2 = 1.5707963705e+00f;
     const uint32_t ux = lm_asuint(x), uy = lm_asuint(y);
     const uint32_t ix = ux & 0x7fffffffu, iy = uy & 0x7fffffffu;
-    const float a = __builtin_fabsf(y / x);  // atanf argument, >= 0
+    // only an infinite or NaN operand needs the general routine
+    *special = (ix > 0x7f7fffffu) || (iy > 0x7f7fffffu);
+    const float a = __builtin_fabsf(y / x);  // atanf argument, >= 0 (x == 0: inf or NaN, patched below)
     const uint32_t ia = lm_asuint(a);
-    // ordinary: finite non-zero x and y, x != 1.0, 2^-29 <= |y/x| < 2^25 (which also keeps the
-    // exponent difference k of e_atan2f.c inside (-60, 60))
-    *special = (ix - 1u >= 0x7f7fffffu) || (iy - 1u >= 0x7f7fffffu) || (ux == 0x3f800000u) || (ia < 0x31000000u) ||
-               (ia >= 0x4c000000u);
-    // atanf(a), a > 0: range selection without branches
+    // atanf(a), a >= 0: range selection without branches.  The first range also serves
+    // a < 2^-29, where s_atanf.c returns its argument: t - t*(s1+s2) rounds to t there.
     const bool r0 = ia < 0x3ee00000u;   // a < 7/16
     const bool r1 = ia < 0x3f300000u;   // a < 11/16
     const bool r2 = ia < 0x3f980000u;   // a < 19/16
@@ -278,12 +277,22 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
     const float p = t * (s1 + s2);
-    const float zat = r0 ? (t - p) : (hi - ((p - lo) - t));  // atanf(|y/x|)
-    // quadrant, e_atan2f.c switch (m)
+    float zat = r0 ? (t - p) : (hi - ((p - lo) - t));  // atanf(|y/x|)
+    // a >= 2^25 (also a = inf): s_atanf.c returns hi3 + lo3, and e_atan2f.c's shortcut for an
+    // exponent difference above 60, pi/2 + 0.5*pi_lo, is the same float.  (Its other shortcut,
+    // z = 0 for x < 0 and an exponent difference below -60, changes nothing after z - pi_lo.)
+    zat = (ia >= 0x4c000000u) ? pi_o_2 : zat;
+    // quadrant, e_atan2f.c switch (m); x == 1.0 needs no case of its own: atanf(y) is odd in y
     const bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
     const float q2 = pi - (zat - pi_lo);
     const float q3 = (zat - pi_lo) - pi;
-    return xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+    float r = xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+    // zeros (e_atan2f.c "when y = 0" / "when x = 0"; the +-tiny there is absorbed by rounding)
+    const float ry0 = xneg ? (yneg ? -pi : pi) : y;
+    const float rx0 = yneg ? -pi_o_2 : pi_o_2;
+    r = (ix == 0) ? rx0 : r;
+    r = (iy == 0) ? ry0 : r;
+    return r;
 }
 
 // sinf / cosf for |y| < 120 as one straight line: reduce_fast with n = 0 is the identity for

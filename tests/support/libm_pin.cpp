@@ -52,11 +52,16 @@ int main(int argc, char **argv)
     }
     for (long i = 0; i < n_each; i++) {
         float y, x;
-        switch (i % 5) {
+        switch (i % 8) {
         case 0: y = anyf(); x = anyf(); break;
         case 1: y = (float)(unit() * 4 - 2); x = (float)(unit() * 4 - 2); break;
         case 2: y = (float)((unit() * 4 - 2) * 1e-3); x = (float)(unit() * 4 - 2); break;
         case 3: y = (float)(unit() * 4 - 2); x = (float)((unit() * 4 - 2) * 1e-4); break;
+        case 4: case 5: case 6: {  // one operand from the table of special values, the other arbitrary
+                   const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-40f, 3e38f};
+                   float o = (i % 8 == 4) ? anyf() : (float)((unit() * 4 - 2) * ldexp(1.0, (int)(rnd() % 100) - 50));
+                   if (rnd() & 1) { y = sp[rnd() % 9]; x = o; } else { y = o; x = sp[rnd() % 9]; }
+                   break; }
         default: { const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-40f, 3e38f};
                    y = sp[rnd() % 9]; x = sp[rnd() % 9]; break; }
         }
