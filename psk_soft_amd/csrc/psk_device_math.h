@@ -165,10 +165,10 @@ PSK_DEV float atan2f_wave(float y, float x)
     return atan2f_wave<false>(y, x, unused);
 }
 template <bool LEAN>
-PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special)
+PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special, int dep)
 {
     bool sp;
-    lm_sincosf_ordinary(t, sn, cs, &sp);
+    lm_sincosf_ordinary(t, sn, cs, &sp, dep);
     if (LEAN) {
         special = special || sp;
     } else if (__any(sp)) {

@@ -33,6 +33,9 @@
 
 // keeps the instruction scheduler from interleaving two stages of the block loop (which would
 // overlap their register demands); no instruction is emitted
+#ifndef PSK_PREFETCH
+#define PSK_PREFETCH 0
+#endif
 #ifndef PSK_STAGE_FENCE
 #define PSK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -258,12 +261,13 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         w[1] = incl;
         w[0] = incl - dl1;
     }
+    const double two_pi = PSK_KD(kTwoPi, (int)q0);
     int pass = 0;
     for (;;) {
         double y_d[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
-            double yd = rawd[r] + (double)(long long)w[r] * kTwoPi;  // cpp/psk_soft.cpp:478
+            double yd = rawd[r] + (double)(long long)w[r] * two_pi;  // cpp/psk_soft.cpp:478
             y[r] = (float)yd;                                         // next(float yval), :481
             if (valid[r])
                 yring[before[r] & kYMask] = y[r];
@@ -448,9 +452,15 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     if constexpr (H == 1)
         ering_put<S>(ering, kB, lane, hist[0].e);  // block -1
 
+    // the samples of a block are requested one block ahead (numAvg <= 128: while the phase half
+    // of the previous block runs), so that their latency is not on the critical path of the wave
+    constexpr bool PREFETCH = (H == 1) && PSK_PREFETCH;
+    float2 xn[kR][S];
+    if constexpr (PREFETCH)
+        load_block<S>(X, 0, A, 0, tau_last, lane, xn);
     for (int c = 0; c < n_blocks; c++) {
-        float2 xn[kR][S];
-        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+        if constexpr (!PREFETCH)
+            load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -637,6 +647,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
 
+        if constexpr (PREFETCH)
+            load_block<S>(X, (long long)c + 1, A, 0, tau_last, lane, xn);  // (past the end: zero-filled, no access)
         PSK_STAGE_FENCE();
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
         // The screened kernel carries only the straight-line forms of atan2f / sincosf and of the
@@ -696,10 +708,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
             }
             if (M == 4)
-                phaseCorrection = (float)((double)phaseCorrection + kPi4);
+                phaseCorrection = (float)((double)phaseCorrection + PSK_KD(kPi4, c));
             float sn, cs;
             bool sp = false;
-            sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp);
+            sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp, c);
             special = special || (valid[r] && sp);
             cf32 ph;
             ph.re = 1.0f * cs;

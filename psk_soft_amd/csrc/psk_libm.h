@@ -32,6 +32,25 @@
 
 namespace psk {
 
+// A double constant for use inside the block loop of a kernel.  Left to itself the compiler hoists
+// such constants out of the loop into scalar register pairs, runs out of scalar registers, and
+// parks them in lanes of a vector register -- every use then costs vector-ALU instructions to
+// fetch them back.  PSK_KD materialises the constant with two scalar moves where it is used;
+// `dep` is any value that changes per loop iteration (it only pins the moves inside the loop).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <uint64_t BITS>
+__device__ __forceinline__ double lm_kd(int dep)
+{
+    int lo, hi;
+    asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"((uint32_t)BITS), "s"(dep));
+    asm("s_mov_b32 %0, %1" : "=s"(hi) : "i"((uint32_t)(BITS >> 32)), "s"(dep));
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+#define PSK_KD(val, dep) psk::lm_kd<__builtin_bit_cast(uint64_t, (double)(val))>(dep)
+#else
+#define PSK_KD(val, dep) ((double)(val))
+#endif
+
 PSK_HD uint32_t lm_asuint(float f) { return __builtin_bit_cast(uint32_t, f); }
 PSK_HD float lm_asfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
 
@@ -297,12 +316,14 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
 
 // sinf / cosf for |y| < 120 as one straight line: reduce_fast with n = 0 is the identity for
 // |y| < pi/4, so the two ranges of s_sinf.c share the code; tiny |y| is patched at the end
-PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special)
+PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, int dep = 0)
 {
-    const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;
-    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
-                 C4 = 0x1.99343027bf8c3p-16;
-    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const double HPI_INV = PSK_KD(0x1.45F306DC9C883p+23, dep), HPI = PSK_KD(0x1.921FB54442D18p0, dep);
+    const double C1 = PSK_KD(-0x1.ffffffd0c621cp-2, dep), C2 = PSK_KD(0x1.55553e1068f19p-5, dep),
+                 C3 = PSK_KD(-0x1.6c087e89a359dp-10, dep), C4 = PSK_KD(0x1.99343027bf8c3p-16, dep);
+    const double S1 = PSK_KD(-0x1.555545995a603p-3, dep), S2 = PSK_KD(0x1.1107605230bc4p-7, dep),
+                 S3 = PSK_KD(-0x1.994eb3774cf24p-13, dep);
+    const double C0 = 0x1p0;
     const uint32_t top = lm_abstop12(y);
     *special = top >= lm_abstop12(120.0f);
     const double x = (double)y;
