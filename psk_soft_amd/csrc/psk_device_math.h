@@ -178,18 +178,21 @@ PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special, int dep)
 }
 
 // (long) of a double as x86-64 cvttsd2si does it (cpp/psk_soft.cpp:477, 598)
-PSK_DEV long long to_long_x86(double v)
+PSK_DEV long long to_long_x86(double v, int dep = 0)
 {
-    if (!(v < 9223372036854775808.0) || v < -9223372036854775808.0)  // also NaN
+    const double lim = PSK_KD(9223372036854775808.0, dep);
+    if (!(v < lim) || v < -lim)  // also NaN
         return (long long)0x8000000000000000ull;
     return (long long)v;
 }
 
 // numWraps = round((phaseEstimate-thisPhase)/M_2PI)  (cpp/psk_soft.cpp:477)
-PSK_DEV long long unwrap_count(float phaseEstimate, double thisPhase)
+// (dep: see PSK_KD -- any per-iteration value when called inside a loop)
+PSK_DEV long long unwrap_count(float phaseEstimate, double thisPhase, int dep = 0)
 {
     // the quotient is bit-identical to the IEEE division (lm_div_known)
-    return to_long_x86(__builtin_round(lm_div_known((double)phaseEstimate - thisPhase, kTwoPi, kInvTwoPi)));
+    return to_long_x86(
+        __builtin_round(lm_div_known((double)phaseEstimate - thisPhase, PSK_KD(kTwoPi, dep), PSK_KD(kInvTwoPi, dep))), dep);
 }
 
 // LinearFit::calculateDenominator (cpp/psk_soft.cpp:176-185): C pow(double,double) on

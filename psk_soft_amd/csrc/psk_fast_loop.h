@@ -318,8 +318,8 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             if (__all(sure0 && sure1))
                 break;
         }
-        int w2_0 = (int)unwrap_count(est_prev0, rawd[0]);  // cpp/psk_soft.cpp:477 with the true feedback
-        int w2_1 = (int)unwrap_count(est[0], rawd[1]);
+        int w2_0 = (int)unwrap_count(est_prev0, rawd[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
+        int w2_1 = (int)unwrap_count(est[0], rawd[1], (int)q0);
         bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
         if (!__any(bad))
             break;

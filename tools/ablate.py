@@ -2,7 +2,7 @@
 skipped (results become wrong on purpose), to attribute instruction counts and time to sections.
 Run it on a throw-away copy of the tree (the GPU box snapshot), never commit its output.
 
-usage: python tools/ablate.py <section> [<section> ...]   sections: atan sincos fit scan rot pow
+usage: python tools/ablate.py <section> [<section> ...]   sections: atan sincos fit scan argmax out rot pow
 """
 import sys
 
@@ -18,9 +18,9 @@ def swap(old, new):
 
 for sec in sys.argv[1:]:
     if sec == "atan":
-        swap("rawd[r] = (double)atan2f_wave(pw.im, pw.re);", "rawd[r] = (double)(pw.im + pw.re);")
+        swap("rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp);", "rawd[r] = (double)(pw.im + pw.re);")
     elif sec == "sincos":
-        swap("sincosf_wave(phaseCorrection, &sn, &cs);", "sn = phaseCorrection; cs = 1.0f - phaseCorrection;")
+        swap("sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp, c);", "sn = phaseCorrection; cs = 1.0f - phaseCorrection;")
     elif sec == "pow":
         swap("cf32 pw = cpow_uint<false>(s[r], M);", "cf32 pw = s[r];")
     elif sec == "fit":
@@ -31,7 +31,11 @@ for sec in sys.argv[1:]:
             "            pass = fit_block<false>(",
         )
     elif sec == "scan":
-        swap("float incl = wave_scan_f32(d0 + d1);", "float incl = d0 + d1;")
+        swap("            wave_scan_f32_multi<S>(inc);\n", "")
+    elif sec == "argmax":
+        swap("                    m2[0] = med3_i32(m1[0], m2[0], p0);\n                    m2[1] = med3_i32(m1[1], m2[1], p1);\n", "")
+    elif sec == "out":
+        swap("        if (valid[1]) {\n            typedef float f4u", "        if (false) {\n            typedef float f4u")
     elif sec == "rot":
         swap("    return bperm_addr(p.src_addr[r], offered);", "    return offered;")
     else:
