@@ -371,6 +371,7 @@ PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int 
 template <int S, int H, bool EXACT>
 PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *ering, FastCarry &cy)
 {
+
     const int lane = threadIdx.x & 63;
     const uint32_t A = p.A, M = p.M, n = p.lf_n;
     const int n_out = (int)p.n_out;  // <= 2^20 on this path
@@ -615,16 +616,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             cy.stat_exact_blocks += 1;
         }
 
-        // sampleIndex_dataShort_out (reference cpp/psk_soft.cpp:466) goes out at once
-        if (p.sidx) {
-            typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
-            if (valid[1]) {
-                s2u v = {(short)(unsigned short)bestK[0], (short)(unsigned short)bestK[1]};
-                *reinterpret_cast<s2u *>(p.sidx + i0) = v;
-            } else if (valid[0]) {
-                p.sidx[i0] = (int16_t)(unsigned short)bestK[0];
-            }
-        }
         cy.last_k = (uint32_t)__builtin_amdgcn_readlane(r_last ? bestK[1] : bestK[0], lane_last);
 
         // the sample to output: kept at a predicted index -- verify, else re-read (rare, exact either way)
@@ -640,6 +631,18 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             s[r].re = px[r];
             s[r].im = py[r];
             kpred[r] = valid[r] ? bestK[r] : kpred[r];
+        }
+
+        // sampleIndex_dataShort_out (reference cpp/psk_soft.cpp:466) --
+        // after the re-read above, whose wait would otherwise also wait for this store
+        if (p.sidx) {
+            typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
+            if (valid[1]) {
+                s2u v = {(short)(unsigned short)bestK[0], (short)(unsigned short)bestK[1]};
+                *reinterpret_cast<s2u *>(p.sidx + i0) = v;
+            } else if (valid[0]) {
+                p.sidx[i0] = (int16_t)(unsigned short)bestK[0];
+            }
         }
 
         // history for the next block
