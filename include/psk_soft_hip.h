@@ -115,7 +115,8 @@ typedef struct psk_soft_stats {
     uint64_t channels_guard;      /* of those: sent there at run time by the exactness guard       */
     uint64_t unwrap_extra_passes; /* extra unwrap fixed-point passes summed over all 128-symbol blocks */
     uint64_t unwrap_blocks;       /* 128-symbol blocks processed by the wave-scan kernel           */
-    uint64_t timing_exact_blocks; /* of those: blocks whose timing argmax needed the exact double pass */
+    uint64_t timing_exact_blocks; /* of those: blocks whose timing argmax needed the exact double pass
+                                     (in the screened kernel, numAvg <= 128, or in the exact kernel) */
 } psk_soft_stats_t;
 
 uint32_t psk_soft_abi_version(void);

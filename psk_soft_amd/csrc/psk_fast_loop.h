@@ -368,6 +368,50 @@ PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int 
     return read_lane(wave_scan_f32(acc), 63);
 }
 
+// The timing argmax of one block redone exactly from the LDS energy ring (numAvg <= 128), for the
+// screened kernel when its margin test fails somewhere in the block: window sums of float-valued
+// energies accumulated in double (exact under the exponent-spread guard, which is fed here and
+// evaluated at the end of the kernel), the reference's first-maximum rule
+// (cpp/psk_soft.cpp:445-466).  Also returns the exact sums at the block's last position, rounded to
+// float, as fresh carries for the screening pass.  `base` = ring offset of the current block.
+template <int S>
+PSK_DEV void exact_block_from_ring(const float *ering, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
+                                   float (&Wf)[S])
+{
+    const int prev = base ^ kB;
+    const int i_old0 = (base + 2 * lane - (int)A) & (kERing - 1);
+    const int i_old1 = (i_old0 + 1) & (kERing - 1);
+    const bool in0 = 2 * lane >= kB - (int)A, in1 = 2 * lane + 1 >= kB - (int)A;
+    double bestW[kR] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < S; k++) {  // (unrolled: Wf[] must stay in registers)
+        const float *row = ering + k * kERing;
+        const float2 en = *reinterpret_cast<const float2 *>(row + base + 2 * lane);
+        const float2 ep = *reinterpret_cast<const float2 *>(row + prev + 2 * lane);
+        const float eo0 = row[i_old0], eo1 = row[i_old1];
+        guard_track(cy, en.x);
+        guard_track(cy, en.y);
+        guard_track(cy, ep.x);
+        guard_track(cy, ep.y);
+        guard_track(cy, eo0);
+        guard_track(cy, eo1);
+        // the window ending at the previous block's last position: its positions >= kB - A
+        const double Wc = wave_sum_f64((in0 ? (double)ep.x : 0.0) + (in1 ? (double)ep.y : 0.0));
+        const double d0 = (double)en.x - (double)eo0, d1 = (double)en.y - (double)eo1;
+        const double W1 = Wc + wave_scan_f64(d0 + d1);
+        const double W0 = W1 - d1;
+        if (k == 0 || bestW[0] < W0) {  // std::max_element: first maximum, strict '<'
+            bestW[0] = W0;
+            bestK[0] = k;
+        }
+        if (k == 0 || bestW[1] < W1) {
+            bestW[1] = W1;
+            bestK[1] = k;
+        }
+        Wf[k] = uni((float)read_lane(W1, 63));
+    }
+}
+
 template <int S, int H, bool EXACT>
 PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *ering, FastCarry &cy)
 {
@@ -587,8 +631,16 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             since_refresh++;
             // a near-tie (or a non-finite energy) anywhere: the call goes to the exact kernel
             if (!__all(ok0 && ok1)) {
-                cy.refuse = true;
-                return;
+                if constexpr (H == 1) {
+                    // settle this block exactly, here; the exact sums also refresh the float carries
+                    exact_block_from_ring<S>(ering, (c & 1) * kB, A, lane, cy, bestK, Wf);
+                    err_c = 2.0f * kU * wmax_prev;
+                    since_refresh = 0;
+                    cy.stat_exact_blocks += 1;
+                } else {
+                    cy.refuse = true;
+                    return;
+                }
             }
         } else {
             // ---- exact pass: float-valued addends summed in double ----

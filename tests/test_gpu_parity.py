@@ -175,36 +175,43 @@ def test_edge_packets(oracle_mod):
     h.close()
 
 
-def test_tie_heavy_signal_takes_the_exact_timing_kernel(oracle_mod):
+def test_tie_heavy_signal_takes_the_exact_timing_path(oracle_mod):
     """Rectangular pulses (the reference test's own stimulus): every intra-symbol phase has the
-    same energy up to noise, the float screening cannot vouch for the argmax and must hand the
-    call to the exact-timing kernel, whose first-maximum tie rule has to match the reference."""
+    same energy up to noise, the float screening cannot vouch for the argmax.  For numAvg <= 128
+    the screened kernel settles such blocks itself, exactly, from its energy ring; for larger
+    windows it hands the call to the exact-timing kernel.  Either way the first-maximum tie rule
+    has to match the reference."""
     import random as _random
 
     from psk_soft_amd.stimulus import gen_psk
 
     data, _ = gen_psk(3000, samp_per_baud=8, num_syms=4, differential=False, rng=_random.Random(11))
-    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100)
-    ref = oracle_run(oracle_mod, data, props, packet=8192)
-    h = _handle()
-    h.configure(0, [props])
-    got = run_gpu(h, 0, data, 0.01, 8192)
-    st = h.stats()
-    assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
-    assert_parity(got, ref, "ties")
+    for numAvg, in_kernel in ((100, True), (200, False)):
+        props = dict(samplesPerBaud=8, constelationSize=4, numAvg=numAvg)
+        ref = oracle_run(oracle_mod, data, props, packet=8192)
+        h = _handle()
+        h.configure(0, [props])
+        got = run_gpu(h, 0, data, 0.01, 8192)
+        st = h.stats()  # of the last call: steady state
+        assert st["channels_sequential"] == 0 and st["timing_exact_blocks"] > 0, st
+        assert st["channels_exact_timing"] == (0 if in_kernel else 1), st
+        assert_parity(got, ref, "ties numAvg=%d" % numAvg)
+        h.close()
     # exact ties: a constant-envelope signal with NO noise at all
-    k = np.random.default_rng(1).integers(0, 4, 2000)
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100)
+    k = np.random.default_rng(1).integers(0, 4, 6000)
     x = np.repeat(np.exp(2j * np.pi * k / 4 + 0.2j), 8)
     iq = np.empty(2 * x.size, np.float32)
     iq[0::2] = x.real
     iq[1::2] = x.imag
-    ref = oracle_run(oracle_mod, iq, props)
+    ref = oracle_run(oracle_mod, iq, props, packet=16000)
     h2 = _handle()
     h2.configure(0, [props])
-    got = run_gpu(h2, 0, iq, 0.01)
-    assert h2.stats()["channels_exact_timing"] == 1
+    got = run_gpu(h2, 0, iq, 0.01, 16000)
+    st = h2.stats()
+    assert st["channels_sequential"] == 0 and st["channels_exact_timing"] == 0 and st["timing_exact_blocks"] > 0, st
     assert_parity(got, ref, "exact ties")
-    h.close(); h2.close()
+    h2.close()
 
 
 def test_random_configuration_sweep(oracle_mod):
