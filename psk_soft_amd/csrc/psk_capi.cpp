@@ -8,10 +8,16 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "psk_ctl.h"
@@ -43,6 +49,111 @@ psk_soft_status fail(psk_soft_status st, const std::string &msg)
     } while (0)
 
 constexpr int kPlanSlots = 4;
+constexpr int kStageSlots = 3;  // chunks of the host-buffer path in flight (< kPlanSlots)
+
+// Minimal fork-join pool for the host-buffer path: packing packets into pinned memory and
+// unpacking results are plain memcpy work that one thread cannot do at PCIe rate.
+class CopyPool {
+public:
+    explicit CopyPool(int n_threads)
+    {
+        for (int t = 0; t < n_threads; t++) workers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    // fn(i) for i in [0, n); the caller takes part; returns when all are done
+    void run(uint32_t n, const std::function<void(uint32_t)> &fn)
+    {
+        if (!n)
+            return;
+        if (workers_.empty() || n == 1) {
+            for (uint32_t i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            busy_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            uint32_t i = next_.fetch_add(1);
+            if (i >= n_)
+                break;
+            (*fn_)(i);
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_)
+                    return;
+                seen = gen_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--busy_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(uint32_t)> *fn_ = nullptr;
+    uint32_t n_ = 0;
+    std::atomic<uint32_t> next_{0};
+    int busy_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
+// packets and the packed four output streams, its own stream (so that the upload of one chunk, the
+// kernels of another and the download of a third overlap), and an event for "outputs are in host
+// memory".
+struct StageSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t *h_buf = nullptr;  // pinned: [in | soft | phase | bits | sidx]
+    uint8_t *d_buf = nullptr;
+    size_t in_cap = 0;         // bytes of the input region; the others follow as IN, IN/2, IN, IN/4
+    bool busy = false;
+    // what the chunk in flight needs for unpacking
+    uint32_t ch0 = 0, nch = 0;
+    std::vector<size_t> off_soft, off_phase, off_bits, off_sidx;
+    size_t soft_bytes = 0, phase_bytes = 0, bits_bytes = 0, sidx_bytes = 0;
+};
+inline size_t region_soft(size_t in_cap) { return in_cap; }
+inline size_t region_phase(size_t in_cap) { return in_cap + in_cap; }
+inline size_t region_bits(size_t in_cap) { return in_cap + in_cap + in_cap / 2; }
+inline size_t region_sidx(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap; }
+inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap + in_cap / 4; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 384;  // LDS y ring of the wave-scan kernel: 512 - 128
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2, 4, 5, 8, 10, 16};
@@ -67,13 +178,10 @@ struct psk_soft_handle {
     bool ev_used[kPlanSlots] = {};
     int slot = 0;
     hipStream_t stream = nullptr;
-    // staging for the host-buffer entry point
-    float *d_in = nullptr;
-    float *d_soft = nullptr;
-    float *d_phase = nullptr;
-    int16_t *d_bits = nullptr;
-    int16_t *d_sidx = nullptr;
-    uint64_t stage_cap = 0;  // symbols per channel
+    // ingest pipeline of the host-buffer entry point (psk_soft_process_host)
+    StageSlot stage[kStageSlots];
+    CopyPool *pool = nullptr;
+    size_t stage_bytes = 32u << 20;  // input bytes per chunk (PSK_SOFT_STAGE_MB)
 };
 
 extern "C" {
@@ -179,11 +287,14 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
         if (h->d_state) (void)hipFree(h->d_state);
         if (h->d_ring) (void)hipFree(h->d_ring);
         if (h->d_yv) (void)hipFree(h->d_yv);
-        if (h->d_in) (void)hipFree(h->d_in);
-        if (h->d_soft) (void)hipFree(h->d_soft);
-        if (h->d_phase) (void)hipFree(h->d_phase);
-        if (h->d_bits) (void)hipFree(h->d_bits);
-        if (h->d_sidx) (void)hipFree(h->d_sidx);
+        for (auto &sl : h->stage) {
+            if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+            if (sl.h_buf) (void)hipHostFree(sl.h_buf);
+            if (sl.d_buf) (void)hipFree(sl.d_buf);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        }
+        delete h->pool;
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -316,6 +427,54 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     return PSK_SOFT_OK;
 }
 
+// ---- host-buffer path: the ingest pipeline --------------------------
+// The batch is cut into chunks of channels of about `stage_bytes` of input each.  Per chunk: the
+// packets are packed into pinned memory (CopyPool), uploaded with ONE copy, processed, and the four
+// output streams -- packed tightly, their sizes are known from the plan -- come back with one copy
+// each and are scattered to the caller's buffers.  kStageSlots chunks are in flight on separate
+// streams, so upload, kernels, download and the two host-side copies of different chunks overlap.
+static psk_soft_status stage_ensure(psk_soft_handle *h, StageSlot &sl, size_t in_bytes)
+{
+    if (!sl.stream) {
+        PSK_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        PSK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    if (sl.in_cap >= in_bytes)
+        return PSK_SOFT_OK;
+    size_t cap = align_up(in_bytes > h->stage_bytes ? in_bytes : h->stage_bytes, 4096);
+    if (sl.h_buf) (void)hipHostFree(sl.h_buf);
+    if (sl.d_buf) (void)hipFree(sl.d_buf);
+    sl.h_buf = nullptr;
+    sl.d_buf = nullptr;
+    sl.in_cap = 0;
+    PSK_HIP(hipHostMalloc((void **)&sl.h_buf, region_total(cap)));
+    PSK_HIP(hipMalloc((void **)&sl.d_buf, region_total(cap)));
+    sl.in_cap = cap;
+    return PSK_SOFT_OK;
+}
+
+// results of the chunk in `sl` -> the caller's buffers
+static psk_soft_status stage_retire(psk_soft_handle *h, StageSlot &sl, psk_soft_output_t *outs, uint32_t batch_ch0)
+{
+    if (!sl.busy)
+        return PSK_SOFT_OK;
+    PSK_HIP(hipEventSynchronize(sl.done));
+    const uint8_t *hs = sl.h_buf + region_soft(sl.in_cap), *hp = sl.h_buf + region_phase(sl.in_cap);
+    const uint8_t *hb = sl.h_buf + region_bits(sl.in_cap), *hx = sl.h_buf + region_sidx(sl.in_cap);
+    psk_soft_output_t *o0 = outs + (sl.ch0 - batch_ch0);
+    h->pool->run(sl.nch, [&](uint32_t i) {
+        const psk_soft_output_t &o = o0[i];
+        if (!o.n_symbols)
+            return;
+        if (o.soft) std::memcpy(o.soft, hs + sl.off_soft[i], sizeof(float) * 2 * o.n_symbols);
+        if (o.phase) std::memcpy(o.phase, hp + sl.off_phase[i], sizeof(float) * o.n_symbols);
+        if (o.bits && o.n_bits) std::memcpy(o.bits, hb + sl.off_bits[i], sizeof(int16_t) * o.n_bits);
+        if (o.sampleIndex && o.n_sampleIndex) std::memcpy(o.sampleIndex, hx + sl.off_sidx[i], sizeof(int16_t) * o.n_sampleIndex);
+    });
+    sl.busy = false;
+    return PSK_SOFT_OK;
+}
+
 psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, const psk_soft_packet_t *pkts,
                                       psk_soft_output_t *outs)
 {
@@ -326,70 +485,155 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
         return psk_soft_process_device(h, ch0, nch, pk.data(), outs, nullptr);
     }
     PSK_HIP(hipSetDevice(h->device));
-    const uint64_t in_cap = h->user.max_packet_complex;
-    const uint64_t out_cap = (in_cap + 3) & ~1ull;  // even: every channel's rows stay 4-byte aligned
-    if (!h->d_in) {
-        const size_t n = h->nch;
-        PSK_HIP(hipMalloc((void **)&h->d_in, sizeof(float) * 2 * in_cap * n));
-        PSK_HIP(hipMalloc((void **)&h->d_soft, sizeof(float) * 2 * out_cap * n));
-        PSK_HIP(hipMalloc((void **)&h->d_phase, sizeof(float) * out_cap * n));
-        PSK_HIP(hipMalloc((void **)&h->d_bits, sizeof(int16_t) * 4 * out_cap * n));
-        PSK_HIP(hipMalloc((void **)&h->d_sidx, sizeof(int16_t) * out_cap * n));
-        h->stage_cap = out_cap;
+    if (!h->pool) {
+        int nt = 8;
+        if (const char *e = std::getenv("PSK_SOFT_HOST_THREADS")) nt = std::atoi(e);
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)nt > hw) nt = (int)hw;
+        h->pool = new CopyPool(nt > 1 ? nt - 1 : 0);  // the calling thread works too
+        if (const char *e = std::getenv("PSK_SOFT_STAGE_MB")) {
+            long mb = std::atol(e);
+            if (mb >= 1 && mb <= 4096) h->stage_bytes = (size_t)mb << 20;
+        }
     }
-    std::vector<psk_soft_packet_t> dp(pkts, pkts + nch);
-    std::vector<psk_soft_output_t> dout(outs, outs + nch);
+    // validate the whole batch first (all or nothing, as psk_soft_process_device), and learn the
+    // output sizes: they depend only on packet sizes and properties
+    struct Need {
+        size_t in, soft, phase, bits, sidx;
+    };
+    std::vector<Need> need(nch);
     for (uint32_t i = 0; i < nch; i++) {
-        const uint32_t ch = ch0 + i;
-        if (pkts[i].present && pkts[i].n_floats / 2 > in_cap)
+        if (pkts[i].present && pkts[i].n_floats / 2 > h->user.max_packet_complex)
             return fail(PSK_SOFT_ERR_LIMIT, "psk_soft_process_host: packet longer than max_packet_complex");
-        dp[i].data = h->d_in + (size_t)ch * 2 * in_cap;
-        dout[i].soft = h->d_soft + (size_t)ch * 2 * out_cap;
-        dout[i].phase = h->d_phase + (size_t)ch * out_cap;
-        dout[i].bits = h->d_bits + (size_t)ch * 4 * out_cap;
-        dout[i].sampleIndex = h->d_sidx + (size_t)ch * out_cap;
-        dout[i].cap_symbols = out_cap;
-        if (pkts[i].present && pkts[i].n_floats)
-            PSK_HIP(hipMemcpyAsync((void *)dp[i].data, pkts[i].data, sizeof(float) * (pkts[i].n_floats & ~1ull),
-                                   hipMemcpyHostToDevice, h->stream));
-    }
-    // the caller's capacity applies to the caller's buffers
-    for (uint32_t i = 0; i < nch; i++) {
+        if (pkts[i].present && pkts[i].n_floats && !pkts[i].data)
+            return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process_host: null packet data");
         psk::ChanCtl probe = h->ctl[ch0 + i];
         psk::ChanPlan pl;
         psk_soft_output_t o = outs[i];
+        o.cap_symbols = ~0ull;
         psk_soft_status st = psk::plan_call(probe, h->lim, pkts[i], o, pl);
-        if (st == PSK_SOFT_OK && o.n_symbols > outs[i].cap_symbols)
-            return fail(PSK_SOFT_ERR_CAPACITY, "psk_soft_process_host: output buffer too small");
-    }
-    psk_soft_status st = psk_soft_process_device(h, ch0, nch, dp.data(), dout.data(), h->stream);
-    if (st != PSK_SOFT_OK)
-        return st;
-    for (uint32_t i = 0; i < nch; i++) {
-        psk_soft_output_t &o = outs[i];
-        const psk_soft_output_t &d = dout[i];
-        o.ret = d.ret;
-        o.n_symbols = d.n_symbols;
-        o.n_bits = d.n_bits;
-        o.n_sampleIndex = d.n_sampleIndex;
-        o.sri_pushed = d.sri_pushed;
-        o.sri_soft_xdelta = d.sri_soft_xdelta;
-        o.sri_bits_xdelta = d.sri_bits_xdelta;
-        o.n_warn = d.n_warn;
-        if (d.n_symbols) {
-            if (o.soft)
-                PSK_HIP(hipMemcpyAsync(o.soft, d.soft, sizeof(float) * 2 * d.n_symbols, hipMemcpyDeviceToHost, h->stream));
-            if (o.phase)
-                PSK_HIP(hipMemcpyAsync(o.phase, d.phase, sizeof(float) * d.n_symbols, hipMemcpyDeviceToHost, h->stream));
-            if (o.bits && d.n_bits)
-                PSK_HIP(hipMemcpyAsync(o.bits, d.bits, sizeof(int16_t) * d.n_bits, hipMemcpyDeviceToHost, h->stream));
-            if (o.sampleIndex && d.n_sampleIndex)
-                PSK_HIP(hipMemcpyAsync(o.sampleIndex, d.sampleIndex, sizeof(int16_t) * d.n_sampleIndex,
-                                       hipMemcpyDeviceToHost, h->stream));
+        if (st != PSK_SOFT_OK) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "psk_soft_process_host: channel %u refused (status %d)", ch0 + i, (int)st);
+            return fail(st, buf);
         }
+        if (o.n_symbols > outs[i].cap_symbols)
+            return fail(PSK_SOFT_ERR_CAPACITY, "psk_soft_process_host: output buffer too small");
+        need[i].in = pkts[i].present ? align_up(sizeof(float) * (pkts[i].n_floats & ~1ull), 8) : 0;
+        need[i].soft = align_up(sizeof(float) * 2 * o.n_symbols, 8);
+        need[i].phase = align_up(sizeof(float) * o.n_symbols, 8);
+        need[i].bits = align_up(sizeof(int16_t) * o.n_bits, 8);
+        need[i].sidx = align_up(sizeof(int16_t) * o.n_sampleIndex, 8);
     }
-    PSK_HIP(hipStreamSynchronize(h->stream));
-    return PSK_SOFT_OK;
+    std::vector<psk_soft_packet_t> dp;
+    std::vector<psk_soft_output_t> dout;
+    uint32_t first = 0;
+    int turn = 0;
+    psk_soft_status status = PSK_SOFT_OK;
+    while (first < nch && status == PSK_SOFT_OK) {
+        // chunk [first, last): as many channels as fit the five regions of a slot
+        Need sum = {0, 0, 0, 0, 0};
+        const size_t cap = h->stage_bytes;
+        uint32_t last = first;
+        while (last < nch) {
+            const Need &n = need[last];
+            if (last > first && (sum.in + n.in > cap || sum.soft + n.soft > cap || sum.phase + n.phase > cap / 2 ||
+                                 sum.bits + n.bits > cap || sum.sidx + n.sidx > cap / 4))
+                break;
+            sum.in += n.in;
+            sum.soft += n.soft;
+            sum.phase += n.phase;
+            sum.bits += n.bits;
+            sum.sidx += n.sidx;
+            last++;
+        }
+        // a single oversized packet gets a slot grown to fit it
+        size_t want = sum.in;
+        if (sum.soft > want) want = sum.soft;
+        if (2 * sum.phase > want) want = 2 * sum.phase;
+        if (sum.bits > want) want = sum.bits;
+        if (4 * sum.sidx > want) want = 4 * sum.sidx;
+        StageSlot &sl = h->stage[turn];
+        turn = (turn + 1) % kStageSlots;
+        if ((status = stage_retire(h, sl, outs, ch0)) != PSK_SOFT_OK)
+            break;
+        if ((status = stage_ensure(h, sl, want)) != PSK_SOFT_OK)
+            break;
+        const uint32_t n = last - first;
+        sl.ch0 = ch0 + first;
+        sl.nch = n;
+        sl.off_soft.resize(n);
+        sl.off_phase.resize(n);
+        sl.off_bits.resize(n);
+        sl.off_sidx.resize(n);
+        dp.assign(pkts + first, pkts + last);
+        dout.assign(outs + first, outs + last);
+        std::vector<size_t> off_in(n);
+        size_t oi = 0, os = 0, op = 0, ob = 0, ox = 0;
+        uint8_t *d_in = sl.d_buf, *d_soft = sl.d_buf + region_soft(sl.in_cap), *d_phase = sl.d_buf + region_phase(sl.in_cap);
+        uint8_t *d_bits = sl.d_buf + region_bits(sl.in_cap), *d_sidx = sl.d_buf + region_sidx(sl.in_cap);
+        for (uint32_t i = 0; i < n; i++) {
+            const Need &nd = need[first + i];
+            off_in[i] = oi;
+            sl.off_soft[i] = os;
+            sl.off_phase[i] = op;
+            sl.off_bits[i] = ob;
+            sl.off_sidx[i] = ox;
+            dp[i].data = (const float *)(d_in + oi);
+            dout[i].soft = (float *)(d_soft + os);
+            dout[i].phase = (float *)(d_phase + op);
+            dout[i].bits = (int16_t *)(d_bits + ob);
+            dout[i].sampleIndex = (int16_t *)(d_sidx + ox);
+            dout[i].cap_symbols = ~0ull;
+            oi += nd.in;
+            os += nd.soft;
+            op += nd.phase;
+            ob += nd.bits;
+            ox += nd.sidx;
+        }
+        sl.soft_bytes = os;
+        sl.phase_bytes = op;
+        sl.bits_bytes = ob;
+        sl.sidx_bytes = ox;
+        // pack, upload, process, download
+        const psk_soft_packet_t *pk0 = pkts + first;
+        uint8_t *h_in = sl.h_buf;
+        h->pool->run(n, [&](uint32_t i) {
+            if (pk0[i].present && pk0[i].n_floats)
+                std::memcpy(h_in + off_in[i], pk0[i].data, sizeof(float) * (pk0[i].n_floats & ~1ull));
+        });
+        if (oi)
+            PSK_HIP(hipMemcpyAsync(d_in, h_in, oi, hipMemcpyHostToDevice, sl.stream));
+        status = psk_soft_process_device(h, ch0 + first, n, dp.data(), dout.data(), sl.stream);
+        if (status != PSK_SOFT_OK)
+            break;
+        for (uint32_t i = 0; i < n; i++) {
+            psk_soft_output_t &o = outs[first + i];
+            const psk_soft_output_t &d = dout[i];
+            o.ret = d.ret;
+            o.n_symbols = d.n_symbols;
+            o.n_bits = d.n_bits;
+            o.n_sampleIndex = d.n_sampleIndex;
+            o.sri_pushed = d.sri_pushed;
+            o.sri_soft_xdelta = d.sri_soft_xdelta;
+            o.sri_bits_xdelta = d.sri_bits_xdelta;
+            o.n_warn = d.n_warn;
+        }
+        if (os) PSK_HIP(hipMemcpyAsync(sl.h_buf + region_soft(sl.in_cap), d_soft, os, hipMemcpyDeviceToHost, sl.stream));
+        if (op) PSK_HIP(hipMemcpyAsync(sl.h_buf + region_phase(sl.in_cap), d_phase, op, hipMemcpyDeviceToHost, sl.stream));
+        if (ob) PSK_HIP(hipMemcpyAsync(sl.h_buf + region_bits(sl.in_cap), d_bits, ob, hipMemcpyDeviceToHost, sl.stream));
+        if (ox) PSK_HIP(hipMemcpyAsync(sl.h_buf + region_sidx(sl.in_cap), d_sidx, ox, hipMemcpyDeviceToHost, sl.stream));
+        PSK_HIP(hipEventRecord(sl.done, sl.stream));
+        sl.busy = true;
+        first = last;
+    }
+    // drain, oldest first
+    for (int k = 0; k < kStageSlots; k++) {
+        psk_soft_status st = stage_retire(h, h->stage[(turn + k) % kStageSlots], outs, ch0);
+        if (status == PSK_SOFT_OK)
+            status = st;
+    }
+    return status;
 }
 
 psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h)
@@ -403,6 +647,9 @@ psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h)
         if (h->ev_used[s])
             PSK_HIP(hipEventSynchronize(h->ev[s]));
     PSK_HIP(hipStreamSynchronize(h->stream));
+    for (auto &sl : h->stage)
+        if (sl.stream)
+            PSK_HIP(hipStreamSynchronize(sl.stream));
     return PSK_SOFT_OK;
 }
 

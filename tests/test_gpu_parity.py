@@ -422,3 +422,56 @@ def test_call_longer_than_resync_count(oracle_mod):
     assert h.stats()["channels_sequential"] == 1
     assert_parity(got, ref, "long call")
     h.close()
+
+
+def test_host_ingest_pipeline_chunks(oracle_mod, monkeypatch):
+    """psk_soft_process_host cuts a batch into chunks that are packed, uploaded, processed and
+    downloaded on rotating streams.  With a 1 MiB staging size the 48-channel batch below takes a
+    dozen chunks per call (and a single packet larger than the staging size grows its slot);
+    results must not depend on the chunking."""
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    monkeypatch.setenv("PSK_SOFT_STAGE_MB", "1")
+    monkeypatch.setenv("PSK_SOFT_HOST_THREADS", "4")
+    n_ch = 48
+    rng = random.Random(5)
+    props, iqs = [], []
+    for c in range(n_ch):
+        S = rng.choice([8, 8, 10, 4])
+        M = rng.choice([2, 4, 8])
+        props.append(dict(samplesPerBaud=S, constelationSize=M, numAvg=rng.choice([50, 100]), phaseAvg=rng.choice([20, 50])))
+        N = rng.choice([20000, 33000, 50000]) if c != 7 else 200000  # channel 7: 1.6 MB > staging size
+        iqs.append(synth_channel(7000 + c, M, S, N))
+    h = pl.Handle(n_ch, device=0)
+    h.configure(0, props)
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
+    for k in range(2):
+        pk = []
+        for c in range(n_ch):
+            n = iqs[c].size // 2
+            a, b = (0, n // 2) if k == 0 else (n // 2, n)
+            if c == 11 and k == 0:
+                pk.append(None)  # getPacket() returned nothing for this channel
+            else:
+                pk.append(dict(data=iqs[c][2 * a : 2 * b], xdelta=0.01, sriChanged=(k == 0 or c == 11)))
+        res = h.process_host(0, pk)
+        for c in range(n_ch):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    for c in range(n_ch):
+        o = oracle_mod.OracleComponent()
+        for kk, v in props[c].items():
+            setattr(o, kk, v)
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        n = iqs[c].size // 2
+        for k in range(2):
+            if c == 11 and k == 0:
+                continue  # no packet for this channel in the first call
+            a, b = (0, n // 2) if k == 0 else (n // 2, n)
+            r = o.service(iqs[c][2 * a : 2 * b], 0.01, sriChanged=(k == 0 or c == 11))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        g = {k: np.concatenate(v) for k, v in got[c].items()}
+        r = {k: np.concatenate(v) for k, v in ref.items()}
+        assert_parity(g, r, "ingest ch%d" % c)
+    h.close()
