@@ -33,6 +33,9 @@
 
 // keeps the instruction scheduler from interleaving two stages of the block loop (which would
 // overlap their register demands); no instruction is emitted
+#ifndef PSK_PRIO
+#define PSK_PRIO 2
+#endif
 #ifndef PSK_PREFETCH
 #define PSK_PREFETCH 0
 #endif
@@ -504,8 +507,16 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     if constexpr (PREFETCH)
         load_block<S>(X, 0, A, 0, tau_last, lane, xn);
     for (int c = 0; c < n_blocks; c++) {
+#if PSK_PRIO
+        // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
+        // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if constexpr (!PREFETCH)
             load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+#if PSK_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -704,6 +715,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 
         if constexpr (PREFETCH)
             load_block<S>(X, (long long)c + 1, A, 0, tau_last, lane, xn);  // (past the end: zero-filled, no access)
+#if PSK_PRIO >= 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         PSK_STAGE_FENCE();
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
         // The screened kernel carries only the straight-line forms of atan2f / sincosf and of the
@@ -776,6 +790,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 special = special || (valid[r] && is_nan(corr[r].re) && is_nan(corr[r].im));
         }
 
+#if PSK_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         PSK_STAGE_FENCE();
         // ---- four output streams, two symbols per lane ----
         if (valid[1]) {

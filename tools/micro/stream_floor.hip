@@ -118,5 +118,15 @@ int main()
     ms = run<5>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode5 nontemporal stores                : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<6>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode6 nontemporal loads and stores       : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<7>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode7 narrow streams batched x4          : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    // does the power-of-two row stride of the input (2 MiB per channel) matter?  same kernels, padded rows
+    CHECK(hipFree(in));
+    for (size_t pad : {(size_t)64, (size_t)1024 + 64, (size_t)8192 + 192, (size_t)65536 + 1088}) {
+        const size_t rf = row_floats + pad;
+        CHECK(hipMalloc(&in, sizeof(float) * rf * C)); CHECK(hipMemset(in, 0x3c, sizeof(float) * rf * C));
+        float m0 = run<0>(in, rf, n_blocks, soft, phase, sidx, bits, cap, C);
+        float m2 = run<2>(in, rf, n_blocks, soft, phase, sidx, bits, cap, C);
+        printf("row pad %6zu floats: mode0 %.3f ms  mode2 (loads only) %.3f ms\n", pad, m0, m2);
+        CHECK(hipFree(in));
+    }
     return 0;
 }
