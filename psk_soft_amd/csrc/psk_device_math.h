@@ -146,11 +146,41 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
 // LEAN = true leaves the general routine out of the instruction stream altogether: a special
 // argument is only reported (special |= ...) and the caller hands the whole call to the next
 // kernel tier, which has the general routine.
-template <bool LEAN>
-PSK_DEV float atan2f_wave(float y, float x, bool &special)
+// The range table of the straight-line atan2f (LmAtanTabHost) held in registers: row `which` lives
+// in the first five lanes of one VGPR and an entry is fetched with ds_bpermute -- one LDS-crossbar
+// instruction instead of a chain of selects, and fewer registers than the broadcast constants.
+struct AtanTabDev {
+    int row[6];
+    PSK_DEV float get(int which, int id) const
+    {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(id << 2, row[which]));
+    }
+    PSK_DEV static bool any(bool v) { return __any(v); }
+};
+PSK_DEV AtanTabDev atan_tab_dev(int lane)
+{
+    AtanTabDev t;
+    const LmAtanTabHost h;
+#pragma unroll
+    for (int which = 0; which < 6; which++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int id = 0; id < 5; id++) v = (lane == id) ? h.get(which, id) : v;
+        t.row[which] = __float_as_int(v);
+    }
+    return t;
+}
+// (every lane of the wave must be active where the table form is used: ds_bpermute reads lanes 0-4)
+struct AtanTabWave {
+    PSK_DEV float get(int which, int id) const { return LmAtanTabHost().get(which, id); }
+    PSK_DEV static bool any(bool v) { return __any(v); }
+};
+
+template <bool LEAN, class Tab>
+PSK_DEV float atan2f_wave(float y, float x, bool &special, const Tab &tab)
 {
     bool sp;
-    float r = lm_atan2f_ordinary(y, x, &sp);
+    float r = lm_atan2f_ordinary_t(y, x, &sp, tab);
     if (LEAN) {
         special = special || sp;
     } else if (__any(sp)) {
@@ -162,7 +192,7 @@ PSK_DEV float atan2f_wave(float y, float x, bool &special)
 PSK_DEV float atan2f_wave(float y, float x)
 {
     bool unused = false;
-    return atan2f_wave<false>(y, x, unused);
+    return atan2f_wave<false>(y, x, unused, AtanTabWave());
 }
 template <bool LEAN>
 PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special, int dep)
@@ -289,10 +319,10 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 }
 
 // 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
-template <bool LEAN>
-PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special)
+template <bool LEAN, class Tab>
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special, const Tab &tab)
 {
-    float theta = atan2f_wave<LEAN>(c_im, c_re, special);
+    float theta = atan2f_wave<LEAN>(c_im, c_re, special, tab);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)
         softsym = softsym + 8.0f;
@@ -308,7 +338,7 @@ PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special)
 PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
 {
     bool unused = false;
-    return slice_8psk<false>(c_re, c_im, unused);
+    return slice_8psk<false>(c_re, c_im, unused, AtanTabWave());
 }
 
 }  // namespace psk

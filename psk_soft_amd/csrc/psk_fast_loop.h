@@ -495,6 +495,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         }
     }
     const int n_blocks = (n_out + kB - 1) / kB;
+    const AtanTabDev atab = atan_tab_dev(lane);  // range table of the straight-line atan2f
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
     if constexpr (H == 1)
@@ -732,7 +733,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
                 cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
             bool sp = false;
-            rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp);
+            rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp, atab);
             special = special || (valid[r] && sp);
         }
 
@@ -795,6 +796,15 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 #endif
         PSK_STAGE_FENCE();
         // ---- four output streams, two symbols per lane ----
+        unsigned short sym8[kR] = {0, 0};
+        if (p.bits && p.bpb == 3) {  // 8-PSK slicing with the whole wave active (the atan2f table lives in lanes 0-4)
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                bool sp = false;
+                sym8[r] = slice_8psk<LEAN>(corr[r].re, corr[r].im, sp, atab);
+                special = special || (valid[r] && sp);
+            }
+        }
         if (valid[1]) {
             typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
             typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -817,9 +827,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 s4u v = {(short)(r0 ^ m0), (short)(!m0), (short)(r1 ^ m1), (short)(!m1)};
                 *reinterpret_cast<s4u *>(p.bits + 2 * i0) = v;
             } else if (p.bpb == 3) {
-                bool sp = false;
-                unsigned short a = slice_8psk<LEAN>(corr[0].re, corr[0].im, sp), b = slice_8psk<LEAN>(corr[1].re, corr[1].im, sp);
-                special = special || sp;
+                const unsigned short a = sym8[0], b = sym8[1];
                 s2u v0 = {(short)(a & 1), (short)((a >> 1) & 1)};
                 s2u v1 = {(short)((a >> 2) & 1), (short)(b & 1)};
                 s2u v2 = {(short)((b >> 1) & 1), (short)((b >> 2) & 1)};
@@ -841,9 +849,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 p.bits[2 * i0] = (int16_t)(r0 ^ m0);
                 p.bits[2 * i0 + 1] = (int16_t)(!m0);
             } else if (p.bpb == 3) {
-                bool sp = false;
-                unsigned short a = slice_8psk<LEAN>(corr[0].re, corr[0].im, sp);
-                special = special || sp;
+                const unsigned short a = sym8[0];
                 p.bits[3 * i0] = (int16_t)(a & 1);
                 p.bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
                 p.bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);

@@ -266,10 +266,32 @@ PSK_HD void lm_sincosf(float y, float *sp, float *cp)
 // NaN operand; sincosf: |theta| >= 120, inf, NaN): the caller then takes the general routine above.
 // tests/support/libm_pin.cpp checks fast == general wherever *special is false.
 // ---------------------------------------------------------------------------------
-PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
+// The five argument ranges of s_atanf.c as one table: with t = (c1*a + c0) / (d1*a + d0) and the
+// result hi - ((t*(s1+s2) - lo) - t), every range -- the first one (t = a, result t - t*(s1+s2))
+// included -- runs the same instructions; products with 0, 1 and 2 are exact, so each entry
+// rounds exactly where the reference expression does.  Row `which`, entry `id`:
+//   which: 0 c1, 1 c0, 2 d1, 3 d0, 4 hi, 5 lo;   id: 0 a<7/16, 1 <11/16, 2 <19/16, 3 <39/16, 4 rest
+struct LmAtanTabHost {
+    PSK_HD float get(int which, int id) const
+    {
+        static const float T[6][5] = {
+            {1.0f, 2.0f, 1.0f, 1.0f, 0.0f},
+            {0.0f, -1.0f, -1.0f, -1.5f, -1.0f},
+            {0.0f, 1.0f, 1.0f, 1.5f, 1.0f},
+            {1.0f, 2.0f, 1.0f, 1.0f, 0.0f},
+            {0.0f, 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f},
+            {0.0f, 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f},
+        };
+        return T[which][id];
+    }
+    PSK_HD static bool any(bool v) { return v; }
+};
+
+// Tab::get(which, id) looks a table entry up (the device version keeps each row in the lanes of one
+// register and reads it with ds_bpermute: no select chains); Tab::any(v) is "v holds in some lane".
+template <class Tab>
+PSK_HD float lm_atan2f_ordinary_t(float y, float x, bool *special, const Tab &tab)
 {
-    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
-    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
     const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
                 aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
                 aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
@@ -280,38 +302,46 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
     *special = (ix > 0x7f7fffffu) || (iy > 0x7f7fffffu);
     const float a = __builtin_fabsf(y / x);  // atanf argument, >= 0 (x == 0: inf or NaN, patched below)
     const uint32_t ia = lm_asuint(a);
-    // atanf(a), a >= 0: range selection without branches.  The first range also serves
-    // a < 2^-29, where s_atanf.c returns its argument: t - t*(s1+s2) rounds to t there.
-    const bool r0 = ia < 0x3ee00000u;   // a < 7/16
-    const bool r1 = ia < 0x3f300000u;   // a < 11/16
-    const bool r2 = ia < 0x3f980000u;   // a < 19/16
-    const bool r3 = ia < 0x401c0000u;   // a < 39/16
-    const float num = r0 ? a : r1 ? (2.0f * a - 1.0f) : r2 ? (a - 1.0f) : r3 ? (a - 1.5f) : -1.0f;
-    const float den = r0 ? 1.0f : r1 ? (2.0f + a) : r2 ? (a + 1.0f) : r3 ? (1.0f + 1.5f * a) : a;
-    const float hi = r1 ? hi0 : r2 ? hi1 : r3 ? hi2 : hi3;
-    const float lo = r1 ? lo0 : r2 ? lo1 : r3 ? lo2 : lo3;
-    const float t = r0 ? a : num / den;
+    // atanf(a), a >= 0.  The first range also serves a < 2^-29, where s_atanf.c returns its
+    // argument: t - t*(s1+s2) rounds to t there.
+    const int id = (int)(ia >= 0x3ee00000u) + (int)(ia >= 0x3f300000u) + (int)(ia >= 0x3f980000u) + (int)(ia >= 0x401c0000u);
+    const float c1a = tab.get(0, id) * a, d1a = tab.get(2, id) * a;
+    const float num = c1a + tab.get(1, id);
+    const float den = d1a + tab.get(3, id);
+    const float hi = tab.get(4, id), lo = tab.get(5, id);
+    const float t = num / den;
     const float z = t * t;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
     const float p = t * (s1 + s2);
-    float zat = r0 ? (t - p) : (hi - ((p - lo) - t));  // atanf(|y/x|)
-    // a >= 2^25 (also a = inf): s_atanf.c returns hi3 + lo3, and e_atan2f.c's shortcut for an
-    // exponent difference above 60, pi/2 + 0.5*pi_lo, is the same float.  (Its other shortcut,
-    // z = 0 for x < 0 and an exponent difference below -60, changes nothing after z - pi_lo.)
-    zat = (ia >= 0x4c000000u) ? pi_o_2 : zat;
+    float zat = hi - ((p - lo) - t);  // atanf(|y/x|)
     // quadrant, e_atan2f.c switch (m); x == 1.0 needs no case of its own: atanf(y) is odd in y
     const bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
-    const float q2 = pi - (zat - pi_lo);
-    const float q3 = (zat - pi_lo) - pi;
+    float q2 = pi - (zat - pi_lo);
+    float q3 = (zat - pi_lo) - pi;
     float r = xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
-    // zeros (e_atan2f.c "when y = 0" / "when x = 0"; the +-tiny there is absorbed by rounding)
-    const float ry0 = xneg ? (yneg ? -pi : pi) : y;
-    const float rx0 = yneg ? -pi_o_2 : pi_o_2;
-    r = (ix == 0) ? rx0 : r;
-    r = (iy == 0) ? ry0 : r;
+    // rare operands, patched afterwards:
+    //  * a >= 2^25 (also a = inf): s_atanf.c returns hi3 + lo3, and e_atan2f.c's shortcut for an
+    //    exponent difference above 60, pi/2 + 0.5*pi_lo, is the same float.  (Its other shortcut,
+    //    z = 0 for x < 0 and an exponent difference below -60, changes nothing after z - pi_lo.)
+    //  * zeros (e_atan2f.c "when y = 0" / "when x = 0"; the +-tiny there is absorbed by rounding)
+    const bool rare = (ix == 0) || (iy == 0) || (ia >= 0x4c000000u);
+    if (tab.any(rare)) {
+        zat = (ia >= 0x4c000000u) ? pi_o_2 : zat;
+        q2 = pi - (zat - pi_lo);
+        q3 = (zat - pi_lo) - pi;
+        r = xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+        const float ry0 = xneg ? (yneg ? -pi : pi) : y;
+        const float rx0 = yneg ? -pi_o_2 : pi_o_2;
+        r = (ix == 0) ? rx0 : r;
+        r = (iy == 0) ? ry0 : r;
+    }
     return r;
+}
+PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
+{
+    return lm_atan2f_ordinary_t(y, x, special, LmAtanTabHost());
 }
 
 // sinf / cosf for |y| < 120 as one straight line: reduce_fast with n = 0 is the identity for
