@@ -129,7 +129,11 @@ def main():
 
     # synthetic section-8(d) workload, generated in HBM; every rank draws its own channels
     iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank)
-    cap = N // S + 2
+    # output rows start on 128-byte boundaries in all four streams (64 symbols of the narrowest one):
+    # rows that straddle cache lines cost 8 % of the streaming ceiling (tools/micro/placement_probe.hip)
+    cap = (N // S + 2 + 63) // 64 * 64
+    if os.environ.get("PSK_BENCH_UNALIGNED_ROWS"):  # A/B switch for that measurement
+        cap = N // S + 2
     soft = torch.empty((C, 2 * cap), dtype=torch.float32, device=dev)
     phase = torch.empty((C, cap), dtype=torch.float32, device=dev)
     sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)

@@ -84,6 +84,9 @@ typedef struct psk_soft_packet {
 } psk_soft_packet_t;
 
 /* Where one channel's four output streams go, and what the call produced.
+ * Layout advice for the device-pointer path: start every channel's row of every stream on a
+ * 128-byte boundary (e.g. a row capacity that is a multiple of 64 symbols).  The kernels store
+ * whole cache lines per wave; rows that straddle lines were measured 6 % slower end to end.
  * Pointer fields are inputs; the rest is filled in before the call returns
  * (output sizes depend only on packet sizes and properties, so they are exact
  * even on the asynchronous device-pointer path). */

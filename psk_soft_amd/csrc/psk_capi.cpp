@@ -519,11 +519,13 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
         }
         if (o.n_symbols > outs[i].cap_symbols)
             return fail(PSK_SOFT_ERR_CAPACITY, "psk_soft_process_host: output buffer too small");
-        need[i].in = pkts[i].present ? align_up(sizeof(float) * (pkts[i].n_floats & ~1ull), 8) : 0;
-        need[i].soft = align_up(sizeof(float) * 2 * o.n_symbols, 8);
-        need[i].phase = align_up(sizeof(float) * o.n_symbols, 8);
-        need[i].bits = align_up(sizeof(int16_t) * o.n_bits, 8);
-        need[i].sidx = align_up(sizeof(int16_t) * o.n_sampleIndex, 8);
+        // every channel's rows start on a cache line: rows that straddle lines cost 6-8 % of the
+        // kernel's streaming rate (tools/micro/placement_probe.hip)
+        need[i].in = pkts[i].present ? align_up(sizeof(float) * (pkts[i].n_floats & ~1ull), 128) : 0;
+        need[i].soft = align_up(sizeof(float) * 2 * o.n_symbols, 128);
+        need[i].phase = align_up(sizeof(float) * o.n_symbols, 128);
+        need[i].bits = align_up(sizeof(int16_t) * o.n_bits, 128);
+        need[i].sidx = align_up(sizeof(int16_t) * o.n_sampleIndex, 128);
     }
     std::vector<psk_soft_packet_t> dp;
     std::vector<psk_soft_output_t> dout;

@@ -78,6 +78,22 @@ __global__ __launch_bounds__(64) void k_stream(const float* __restrict__ in, siz
             }
             continue;
         }
+        if (MODE == 8) {
+            // narrow streams every 2nd block: even lanes write the first block's 4 symbols, odd lanes the
+            // second block's (what a pairwise lane exchange would produce): 16 / 16 / 8 bytes per lane
+            if (c & 1) {
+                const size_t base = (size_t)(c - 1) * 128 + (lane & 1) * 128 + (lane >> 1) * 4;
+                f4u pv = {s, acc, s, acc};
+                *reinterpret_cast<f4u*>(ph + base) = pv;
+                typedef short s8u __attribute__((ext_vector_type(8), aligned(4)));
+                typedef short s4u2 __attribute__((ext_vector_type(4), aligned(4)));
+                s8u bv = {1, 0, 1, 0, 1, 0, 1, 0};
+                *reinterpret_cast<s8u*>(bi + 2 * base) = bv;
+                s4u2 xv = {1, 2, 3, 4};
+                *reinterpret_cast<s4u2*>(sx + base) = xv;
+            }
+            continue;
+        }
         f2u p2 = {s, acc};
         *reinterpret_cast<f2u*>(ph + i0) = p2;
         s2u x2 = {(short)(s > 0), (short)(acc > 0)};
@@ -118,6 +134,8 @@ int main()
     ms = run<5>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode5 nontemporal stores                : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<6>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode6 nontemporal loads and stores       : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<7>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode7 narrow streams batched x4          : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    ms = run<8>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode8 narrow streams batched x2 (pairs)   : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    ms = run<0>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode0 again                              : %.3f ms\n", ms);
     // does the power-of-two row stride of the input (2 MiB per channel) matter?  same kernels, padded rows
     CHECK(hipFree(in));
     for (size_t pad : {(size_t)64, (size_t)1024 + 64, (size_t)8192 + 192, (size_t)65536 + 1088}) {
