@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--S", type=int, default=8)
     ap.add_argument("--numAvg", type=int, default=100)
     ap.add_argument("--phaseAvg", type=int, default=50)
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4]: per-channel constelationSize {2,4,8}, phaseAvg {10,50,200}, numAvg {25,100,400}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall seconds of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a few channels against the oracle after the run")
@@ -124,11 +126,27 @@ def main():
 
     C, N, S, M = a.channels, a.nsamp, a.S, a.M
     bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
-    h = pl.Handle(C, device=dev_index, max_window_samples=max(16384, S * a.numAvg), max_phase_avg=max(512, a.phaseAvg))
-    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)
+    if a.mixed:
+        chan_props = [dict(samplesPerBaud=S, constelationSize=(2, 4, 8)[c % 3], phaseAvg=(10, 50, 200)[(c // 3) % 3],
+                           numAvg=(25, 100, 400)[(c // 9) % 3]) for c in range(C)]
+        bpb = 3
+    else:
+        chan_props = [dict(samplesPerBaud=S, constelationSize=M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)] * C
+    h = pl.Handle(C, device=dev_index, max_window_samples=max(16384, S * max(p["numAvg"] for p in chan_props)),
+                  max_phase_avg=max(512, max(p["phaseAvg"] for p in chan_props)))
+    if a.mixed:
+        h.configure(0, chan_props)
+    else:
+        h.configure_all(**chan_props[0])
 
     # synthetic section-8(d) workload, generated in HBM; every rank draws its own channels
-    iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank)
+    if a.mixed:
+        iq = torch.empty((C, 2 * N), dtype=torch.float32, device=dev)
+        for j, Mj in enumerate((2, 4, 8)):
+            idx = torch.arange(j, C, 3, device=dev)
+            iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=0x5EED0000 + rank * 3 + j)
+    else:
+        iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank)
     # output rows start on 128-byte boundaries in all four streams (64 symbols of the narrowest one):
     # rows that straddle cache lines cost 8 % of the streaming ceiling (tools/micro/placement_probe.hip)
     cap = (N // S + 2 + 63) // 64 * 64
@@ -213,7 +231,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%s, samplesPerBaud=%d, %d channels per GPU x %d complex samples per step, numAvg=%d, phaseAvg=%d, "
+            "workload": ("mixed BPSK/QPSK/8-PSK, samplesPerBaud=%d, %d channels per GPU x %d complex samples per step, "
+                         "per-channel phaseAvg {10,50,200} and numAvg {25,100,400}, inputs/outputs resident in HBM" % (S, C, N))
+            if a.mixed else
+            "%s, samplesPerBaud=%d, %d channels per GPU x %d complex samples per step, numAvg=%d, phaseAvg=%d, "
             "inputs/outputs resident in HBM" % ({2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, C, N, a.numAvg, a.phaseAvg),
             "channels_per_gpu": C,
             "samples_per_channel_per_step": N,
@@ -251,16 +272,14 @@ def main():
         worst = 0.0
         for c in (0, C - 1):
             comp = po.OracleComponent()
-            comp.samplesPerBaud = S
-            comp.constelationSize = M
-            comp.numAvg = a.numAvg
-            comp.phaseAvg = a.phaseAvg
+            for kk, vv in chan_props[c].items():
+                setattr(comp, kk, vv)
             x = iq[c].cpu().numpy()
             r = None
             for k in range(a.warmup + a.steps):
                 r = comp.service(x, 0.01, sriChanged=False)
             gs = soft[c, : 2 * n_out].cpu().numpy()
-            gb = bits[c, : bpb * n_out].cpu().numpy()
+            gb = bits[c, : {2: 1, 4: 2, 8: 3}.get(chan_props[c]["constelationSize"], 0) * n_out].cpu().numpy()
             gi = sidx[c, :n_out].cpu().numpy()
             assert np.array_equal(gb, r.bits) and np.array_equal(gi, r.index), "bit/index mismatch on channel %d" % c
             worst = max(worst, float(np.abs(gs - r.soft).max() / np.abs(r.soft).max()))
