@@ -6,10 +6,12 @@
 // written as 16/8/4/8-byte vectors).
 //
 // Input traffic is ONE pass: a symbol is loaded exactly once, when it becomes the newest
-// symbol of a window (A-1 symbols before it is output).  What later steps need from it is kept
-// in registers for H = ceil(A/128) blocks and fetched across lanes with ds_bpermute:
+// symbol of a window (A-1 symbols before it is output).  What later steps need from it stays on chip:
 //   * its S energies  -- subtracted from the window sums A symbols later
-//                        (symbolEnergy[k] -= energy[k], reference cpp/psk_soft.cpp:572-577);
+//                        (symbolEnergy[k] -= energy[k], reference cpp/psk_soft.cpp:572-577).
+//                        numAvg <= 128 (H = 1): in an LDS ring of the last 256 positions;
+//                        larger windows: in registers for H = ceil(A/128) blocks, moved across
+//                        lanes with ds_bpermute;
 //   * ONE of its samples, the one at the timing index the lane chose one block earlier.  When the
 //     symbol is output and the true argmax equals that prediction -- timing is stationary, so
 //     practically always -- the sample is already there; otherwise the lane re-reads it from
@@ -17,11 +19,14 @@
 //
 // Timing argmax (reference cpp/psk_soft.cpp:445-466), two instantiations of the same loop:
 //   EXACT = false  "screened": the window sums are scanned in FLOAT (one fused DPP add per step,
-//                  no double arithmetic) together with a running bound of their rounding error;
+//                  no double arithmetic) together with a running bound E of their rounding error;
 //                  the argmax is accepted only where the best sum beats the runner-up by more
-//                  than twice that bound, i.e. where the exact argmax provably equals it.  If any
-//                  symbol of the call fails the test the wave refuses the call (nothing
+//                  than 6E, i.e. where the exact argmax provably equals it.  A block in which
+//                  some symbol fails that test is redone exactly on the spot from the LDS ring
+//                  (numAvg <= 128); for larger windows the wave refuses the call (nothing
 //                  committed) and the EXACT = true kernel, launched right behind it, redoes it.
+//                  This instantiation also carries only the straight-line libm forms; the rare
+//                  arguments they do not cover make it refuse the call likewise.
 //   EXACT = true   the sums are float-valued addends accumulated in double: exact, hence equal
 //                  to the reference's whatever the summation order (quirk Q8), under the
 //                  exponent-spread guard; near-ties resolve by std::max_element's first-maximum
@@ -30,18 +35,6 @@
 #define PSK_FAST_LOOP_H
 
 #include "psk_wave.h"
-
-// keeps the instruction scheduler from interleaving two stages of the block loop (which would
-// overlap their register demands); no instruction is emitted
-#ifndef PSK_PRIO
-#define PSK_PRIO 2
-#endif
-#ifndef PSK_PREFETCH
-#define PSK_PREFETCH 0
-#endif
-#ifndef PSK_STAGE_FENCE
-#define PSK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 namespace psk {
 
@@ -501,23 +494,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     if constexpr (H == 1)
         ering_put<S>(ering, kB, lane, hist[0].e);  // block -1
 
-    // the samples of a block are requested one block ahead (numAvg <= 128: while the phase half
-    // of the previous block runs), so that their latency is not on the critical path of the wave
-    constexpr bool PREFETCH = (H == 1) && PSK_PREFETCH;
-    float2 xn[kR][S];
-    if constexpr (PREFETCH)
-        load_block<S>(X, 0, A, 0, tau_last, lane, xn);
     for (int c = 0; c < n_blocks; c++) {
-#if PSK_PRIO
         // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
+        // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %)
         __builtin_amdgcn_s_setprio(3);
-#endif
-        if constexpr (!PREFETCH)
-            load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
-#if PSK_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        float2 xn[kR][S];
+        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -562,7 +545,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 for (int r = 0; r < kR; r++) e_old[r][k] = rot_pull<float>(rotE, r, nw, od);
             }
         }
-        PSK_STAGE_FENCE();
         // the sample kept A-1 symbols ago for the symbol now being output, and the index it was kept at
         float px[kR], py[kR];
         int pkk[kR];
@@ -586,7 +568,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             }
         }
 
-        PSK_STAGE_FENCE();
         int bestK[kR] = {0, 0};
         if constexpr (!EXACT) {
             // ---- screening pass in float ----
@@ -714,12 +695,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
 
-        if constexpr (PREFETCH)
-            load_block<S>(X, (long long)c + 1, A, 0, tau_last, lane, xn);  // (past the end: zero-filled, no access)
-#if PSK_PRIO >= 2
         __builtin_amdgcn_s_setprio(0);
-#endif
-        PSK_STAGE_FENCE();
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
         // The screened kernel carries only the straight-line forms of atan2f / sincosf and of the
         // complex multiply / divide; an argument that needs the general routine (zeros, NaN,
@@ -737,7 +713,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             special = special || (valid[r] && sp);
         }
 
-        PSK_STAGE_FENCE();
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
         const uint32_t q0 = cy.q;
         float y[kR], est[kR];
@@ -756,7 +731,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         cy.stat_blocks += 1;
         cy.stat_extra += (uint32_t)pass;
 
-        PSK_STAGE_FENCE();
         // ================= de-rotation and hard decisions (reference cpp/psk_soft.cpp:484-566) =================
         cf32 corr[kR];
 #pragma unroll
@@ -791,10 +765,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 special = special || (valid[r] && is_nan(corr[r].re) && is_nan(corr[r].im));
         }
 
-#if PSK_PRIO == 3
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        PSK_STAGE_FENCE();
         // ---- four output streams, two symbols per lane ----
         unsigned short sym8[kR] = {0, 0};
         if (p.bits && p.bpb == 3) {  // 8-PSK slicing with the whole wave active (the atan2f table lives in lanes 0-4)
