@@ -479,14 +479,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
     const float inv_M = uni(1.0f / (float)(M ? M : 1));
 
-    if constexpr (!EXACT) {
-        // the screened kernel is specialised for the steady state: a call that starts with the fit
-        // window still filling (first phaseAvg symbols after a history clear) goes to the exact kernel
-        if (cy.q < n) {
-            cy.refuse = true;
-            return;
-        }
-    }
     const int n_blocks = (n_out + kB - 1) / kB;
     const AtanTabDev atab = atan_tab_dev(lane);  // range table of the straight-line atan2f
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
@@ -719,10 +711,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         double ySum_l[kR], xySum_l[kR];
         float den_last = den_s, xavg_last = xavg_s;
         int pass;
-        if (!EXACT || __builtin_expect(q0 >= n, 1)) {
+        if (__builtin_expect(q0 >= n, 1)) {
             pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
                                     lane_last, r_last, den_last, xavg_last);
-        } else {  // (the screened kernel never gets here: it leaves warm-up calls to this one)
+        } else {  // the fit window is still filling: the first phaseAvg symbols after a history clear
             pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
                                    lane_last, r_last, den_last, xavg_last);
         }
