@@ -9,7 +9,7 @@ for r in $(seq 1 $reps); do
   i=0
   for lib in "$@"; do
     cp $lib psk_soft_amd/libpsk_soft_hip.so
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --check 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('RUN $i %.4f %s'%(d['roofline']['launch_ms_avg'], d['check']['bits_index_exact']))"
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --check $BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('RUN $i %.4f %s'%(d['roofline']['launch_ms_avg'], d['check']['bits_index_exact']))"
     i=$((i+1))
   done
 done | tee /tmp/ab.log
