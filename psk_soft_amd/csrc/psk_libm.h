@@ -26,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define PSK_HD __host__ __device__ __forceinline__
+#define PSK_HDM __host__ __device__ __forceinline__  // member functions
 #else
 #define PSK_HD static inline
+#define PSK_HDM inline
 #endif
 
 namespace psk {
@@ -272,7 +274,7 @@ PSK_HD void lm_sincosf(float y, float *sp, float *cp)
 // rounds exactly where the reference expression does.  Row `which`, entry `id`:
 //   which: 0 c1, 1 c0, 2 d1, 3 d0, 4 hi, 5 lo;   id: 0 a<7/16, 1 <11/16, 2 <19/16, 3 <39/16, 4 rest
 struct LmAtanTabHost {
-    PSK_HD float get(int which, int id) const
+    PSK_HDM float get(int which, int id) const
     {
         static const float T[6][5] = {
             {1.0f, 2.0f, 1.0f, 1.0f, 0.0f},
@@ -284,7 +286,7 @@ struct LmAtanTabHost {
         };
         return T[which][id];
     }
-    PSK_HD static bool any(bool v) { return v; }
+    PSK_HDM static bool any(bool v) { return v; }
 };
 
 // Tab::get(which, id) looks a table entry up (the device version keeps each row in the lanes of one
