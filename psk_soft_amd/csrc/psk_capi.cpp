@@ -749,6 +749,22 @@ psk_soft_status psk_soft_import_state(psk_soft_handle_t *h, uint32_t ch, const v
     return PSK_SOFT_OK;
 }
 
+void *psk_soft_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        g_last_error = "psk_soft_host_alloc: hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void psk_soft_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
 psk_soft_status psk_soft_peek(const psk_soft_handle_t *h, uint32_t ch, uint64_t *ring_len, uint64_t *index,
                               uint64_t *fit_len)
 {

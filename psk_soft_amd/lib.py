@@ -93,6 +93,8 @@ class Stats(ctypes.Structure):
 
 # every symbol include/psk_soft_hip.h declares
 EXPORTS = (
+    "psk_soft_host_alloc",
+    "psk_soft_host_free",
     "psk_soft_abi_version",
     "psk_soft_last_error",
     "psk_soft_create",
@@ -153,8 +155,29 @@ def load():
     L.psk_soft_export_state.argtypes = [vp, u32, vp, u64]
     L.psk_soft_import_state.argtypes = [vp, u32, vp, u64]
     L.psk_soft_peek.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.psk_soft_host_alloc.argtypes = [ctypes.c_size_t]
+    L.psk_soft_host_alloc.restype = vp
+    L.psk_soft_host_free.argtypes = [vp]
     _lib = L
     return L
+
+
+def host_alloc(n, dtype):
+    """A numpy array of `n` elements in pinned host memory (psk_soft_host_alloc): hand its
+    .ctypes.data to Handle.process_device.  Keep the returned array alive; free with host_free."""
+    import numpy as np
+
+    dt = np.dtype(dtype)
+    p = load().psk_soft_host_alloc(int(n) * dt.itemsize)
+    if not p:
+        raise MemoryError("psk_soft_host_alloc failed: " + load().psk_soft_last_error().decode())
+    buf = (ctypes.c_char * (int(n) * dt.itemsize)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt)
+    return arr
+
+
+def host_free(arr):
+    load().psk_soft_host_free(ctypes.c_void_p(arr.ctypes.data))
 
 
 def _check(status):

@@ -496,3 +496,49 @@ def test_host_ingest_pipeline_chunks(oracle_mod, monkeypatch):
         r = {k: np.concatenate(v) for k, v in ref.items()}
         assert_parity(g, r, "ingest ch%d" % c)
     h.close()
+
+
+def test_zero_copy_from_pinned_host_memory(oracle_mod):
+    """psk_soft_process_device with packets and result buffers in PINNED HOST memory
+    (psk_soft_host_alloc): under HIP unified addressing the kernels read the packets and write the
+    results straight over PCIe, no staging copy at all ('Many streams on one GPU')."""
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    n_ch, N, S, M = 8, 40000, 8, 4
+    iq_np = [synth_channel(8100 + c, M, S, N) for c in range(n_ch)]
+    cap = (N // S + 2 + 63) // 64 * 64
+    iq = pl.host_alloc(n_ch * 2 * N, np.float32).reshape(n_ch, 2 * N)
+    soft = pl.host_alloc(n_ch * 2 * cap, np.float32).reshape(n_ch, 2 * cap)
+    phase = pl.host_alloc(n_ch * cap, np.float32).reshape(n_ch, cap)
+    sidx = pl.host_alloc(n_ch * cap, np.int16).reshape(n_ch, cap)
+    bits = pl.host_alloc(n_ch * 2 * cap, np.int16).reshape(n_ch, 2 * cap)
+    for c in range(n_ch):
+        iq[c] = iq_np[c]
+    h = pl.Handle(n_ch, device=0)
+    h.configure_all(samplesPerBaud=S, constelationSize=M)
+    pk = (pl.Packet * n_ch)()
+    out = (pl.Output * n_ch)()
+    for c in range(n_ch):
+        pk[c].data = iq[c].ctypes.data
+        pk[c].n_floats = 2 * N
+        pk[c].sri_xdelta = 0.01
+        pk[c].sri_mode = 1
+        pk[c].sriChanged = 1
+        pk[c].present = 1
+        out[c].soft = soft[c].ctypes.data
+        out[c].bits = bits[c].ctypes.data
+        out[c].phase = phase[c].ctypes.data
+        out[c].sampleIndex = sidx[c].ctypes.data
+        out[c].cap_symbols = cap
+    h.process_device(0, pk, out)
+    h.synchronize()
+    for c in range(n_ch):
+        n = int(out[c].n_symbols)
+        ref = oracle_run(oracle_mod, iq_np[c], dict(samplesPerBaud=S, constelationSize=M))
+        got = dict(soft=soft[c, : 2 * n].copy(), phase=phase[c, :n].copy(), bits=bits[c, : int(out[c].n_bits)].copy(),
+                   index=sidx[c, : int(out[c].n_sampleIndex)].copy())
+        assert_parity(got, ref, "pinned ch%d" % c)
+    h.close()
+    for a in (iq, soft, phase, sidx, bits):
+        pl.host_free(a.reshape(-1))
