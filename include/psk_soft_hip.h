@@ -159,6 +159,14 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
 psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h);
 psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats);
 
+/* Options of a handle (all default 0 = the reference's behaviour, quirks included).
+ * PSK_SOFT_OPT_QPSK_SIGN_BITMAP: 1 = QPSK bits by the signs of the de-rotated symbol, as the
+ *   constellation diagram at reference cpp/psk_soft.cpp:516-521 describes (A 00, B 01, C 10, D 11,
+ *   least significant bit first), instead of the float->bool conversions of :523-526 that make
+ *   every QPSK bit 0.  Opt-in; takes effect at the next process call. */
+enum { PSK_SOFT_OPT_QPSK_SIGN_BITMAP = 1 };
+psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value);
+
 /* Force every channel through the reference-order (sequential) kernel: 1 on, 0 off. */
 psk_soft_status psk_soft_set_force_sequential(psk_soft_handle_t *h, int on);
 

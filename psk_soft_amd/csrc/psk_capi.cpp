@@ -177,6 +177,7 @@ struct psk_soft_handle {
     hipEvent_t ev[kPlanSlots] = {};
     bool ev_used[kPlanSlots] = {};
     int slot = 0;
+    bool opt_qpsk_sign_map = false;  // PSK_SOFT_OPT_QPSK_SIGN_BITMAP
     hipStream_t stream = nullptr;
     // ingest pipeline of the host-buffer entry point (psk_soft_process_host)
     StageSlot stage[kStageSlots];
@@ -373,6 +374,8 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     for (uint32_t i = 0; i < nch; i++) {
         h->ctl[ch0 + i] = next[i];
         h->last_mode[ch0 + i] = plans[i].mode;
+        if (h->opt_qpsk_sign_map)
+            plans[i].lf_flags |= psk::PLAN_QPSK_SIGN_MAP;
     }
     if (h->dry)
         return PSK_SOFT_OK;
@@ -688,6 +691,16 @@ psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats
         }
     }
     return PSK_SOFT_OK;
+}
+
+psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)
+{
+    if (!h)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "null handle");
+    switch (option) {
+    case PSK_SOFT_OPT_QPSK_SIGN_BITMAP: h->opt_qpsk_sign_map = value != 0; return PSK_SOFT_OK;
+    default: return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: unknown option");
+    }
 }
 
 psk_soft_status psk_soft_set_force_sequential(psk_soft_handle_t *h, int on)

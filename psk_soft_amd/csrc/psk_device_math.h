@@ -305,6 +305,15 @@ PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k)
     return mxv + b;
 }
 
+// QPSK bit pair (cpp/psk_soft.cpp:523-526): `bool real = out.back().real()` is "!= 0" (quirk Q1,
+// the default, bit-exact with the reference); sign_map = the mapping of the diagram at :516-521
+PSK_DEV void qpsk_bits(float re, float im, bool sign_map, int &b0, int &b1)
+{
+    const int r = sign_map ? (re > 0.0f) : (re != 0.0f), m = sign_map ? (im > 0.0f) : (im != 0.0f);
+    b0 = r ^ m;
+    b1 = !m;
+}
+
 // abs(phaseEstimate) > wrapValue with ::abs(int) (quirk Q5, cpp/psk_soft.cpp:596)
 PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 {

@@ -481,6 +481,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 
     const int n_blocks = (n_out + kB - 1) / kB;
     const AtanTabDev atab = atan_tab_dev(lane);  // range table of the straight-line atan2f
+    const bool qpsk_sign_map = (p.lf_flags & PLAN_QPSK_SIGN_MAP) != 0;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
     if constexpr (H == 1)
@@ -784,9 +785,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             } else if (p.bpb == 1) {
                 s2u v = {(short)(corr[0].re < 0), (short)(corr[1].re < 0)};
                 *reinterpret_cast<s2u *>(p.bits + i0) = v;
-            } else if (p.bpb == 2) {  // quirk Q1: float -> bool is "!= 0"
-                int r0 = (corr[0].re != 0), m0 = (corr[0].im != 0), r1 = (corr[1].re != 0), m1 = (corr[1].im != 0);
-                s4u v = {(short)(r0 ^ m0), (short)(!m0), (short)(r1 ^ m1), (short)(!m1)};
+            } else if (p.bpb == 2) {  // quirk Q1 (float -> bool is "!= 0") unless the sign map was asked for
+                int a0, a1, b0, b1;
+                qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
+                qpsk_bits(corr[1].re, corr[1].im, qpsk_sign_map, b0, b1);
+                s4u v = {(short)a0, (short)a1, (short)b0, (short)b1};
                 *reinterpret_cast<s4u *>(p.bits + 2 * i0) = v;
             } else if (p.bpb == 3) {
                 const unsigned short a = sym8[0], b = sym8[1];
@@ -807,9 +810,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             } else if (p.bpb == 1) {
                 p.bits[i0] = (int16_t)(corr[0].re < 0);
             } else if (p.bpb == 2) {
-                int r0 = (corr[0].re != 0), m0 = (corr[0].im != 0);
-                p.bits[2 * i0] = (int16_t)(r0 ^ m0);
-                p.bits[2 * i0 + 1] = (int16_t)(!m0);
+                int a0, a1;
+                qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
+                p.bits[2 * i0] = (int16_t)a0;
+                p.bits[2 * i0 + 1] = (int16_t)a1;
             } else if (p.bpb == 3) {
                 const unsigned short a = sym8[0];
                 p.bits[3 * i0] = (int16_t)(a & 1);

@@ -141,9 +141,10 @@ __device__ void seq_emit_symbol(SeqEmit &E, cf32 sample, int sampleIndex, bool h
     } else if (p.bpb == 1) {
         p.bits[i] = (int16_t)(corr.re < 0);
     } else if (p.bpb == 2) {
-        int r = (corr.re != 0), im = (corr.im != 0);
-        p.bits[2 * i] = (int16_t)(r ^ im);
-        p.bits[2 * i + 1] = (int16_t)(!im);
+        int b0, b1;
+        qpsk_bits(corr.re, corr.im, (p.lf_flags & PLAN_QPSK_SIGN_MAP) != 0, b0, b1);
+        p.bits[2 * i] = (int16_t)b0;
+        p.bits[2 * i + 1] = (int16_t)b1;
     } else if (p.bpb == 3) {
         unsigned short sym = slice_8psk(corr.re, corr.im);
         for (int j = 0; j != 3; j++) {

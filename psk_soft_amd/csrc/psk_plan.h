@@ -21,6 +21,10 @@ enum PlanMode : uint32_t {
 
 enum LfFlags : uint32_t {
     LF_RECOMPUTE = 1u,  // LinearFit::reset() ran: sums rebuilt from yvals, count = 0 (cpp/psk_soft.cpp:110-122)
+    // (not a LinearFit flag; it rides in the same word) opt-in QPSK bit map by the SIGNS of the
+    // de-rotated symbol, as the diagram at cpp/psk_soft.cpp:516-521 describes, instead of the
+    // float->bool conversions of :523-526 that make every bit 0 (quirk Q1)
+    PLAN_QPSK_SIGN_MAP = 2u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582

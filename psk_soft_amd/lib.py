@@ -93,6 +93,7 @@ class Stats(ctypes.Structure):
 
 # every symbol include/psk_soft_hip.h declares
 EXPORTS = (
+    "psk_soft_set_option",
     "psk_soft_host_alloc",
     "psk_soft_host_free",
     "psk_soft_abi_version",
@@ -150,6 +151,7 @@ def load():
     L.psk_soft_synchronize.argtypes = [vp]
     L.psk_soft_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.psk_soft_set_force_sequential.argtypes = [vp, i32]
+    L.psk_soft_set_option.argtypes = [vp, i32, i32]
     L.psk_soft_state_bytes.argtypes = [vp]
     L.psk_soft_state_bytes.restype = u64
     L.psk_soft_export_state.argtypes = [vp, u32, vp, u64]
@@ -237,6 +239,11 @@ class Handle:
 
     def fire_listener(self, ch, which):
         _check(self._L.psk_soft_fire_listener(self._h, ch, which))
+
+    OPT_QPSK_SIGN_BITMAP = 1
+
+    def set_option(self, option, value):
+        _check(self._L.psk_soft_set_option(self._h, int(option), int(value)))
 
     def set_force_sequential(self, on):
         _check(self._L.psk_soft_set_force_sequential(self._h, int(bool(on))))

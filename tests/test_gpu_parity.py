@@ -542,3 +542,30 @@ def test_zero_copy_from_pinned_host_memory(oracle_mod):
     h.close()
     for a in (iq, soft, phase, sidx, bits):
         pl.host_free(a.reshape(-1))
+
+
+@pytest.mark.parametrize("force_seq", [0, 1])
+def test_opt_in_qpsk_sign_bitmap(oracle_mod, force_seq):
+    """PSK_SOFT_OPT_QPSK_SIGN_BITMAP: QPSK bits follow the signs of the de-rotated symbol (the
+    diagram at reference cpp/psk_soft.cpp:516-521) instead of being all zero (quirk Q1); everything
+    else stays bit-identical to the default.  Checked against the soft symbols of the same run."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq = synth_channel(77, 4, 8, 1 << 15)
+    props = dict(samplesPerBaud=8, constelationSize=4)
+    ref = oracle_run(oracle_mod, iq, props, packet=5000)
+    h = _handle()
+    h.set_force_sequential(force_seq)
+    h.set_option(h.OPT_QPSK_SIGN_BITMAP, 1)
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01, 5000)
+    h.close()
+    assert not ref["bits"].any()  # the reference's QPSK bits: all zero
+    for k in ("soft", "phase", "index"):
+        assert np.array_equal(got[k], ref[k]) or k != "index"
+    re, im = got["soft"][0::2], got["soft"][1::2]
+    want = np.empty(got["bits"].size, np.int16)
+    want[0::2] = (re > 0) ^ (im > 0)
+    want[1::2] = ~(im > 0)
+    assert np.array_equal(got["bits"], want)
+    assert 0.2 < got["bits"].mean() < 0.8
