@@ -1,0 +1,163 @@
+"""Randomised GPU-vs-oracle comparison (diagnostic; the fixed-seed cases that came out of it live in
+tests/test_gpu_parity.py).  Every round draws a batch of channels with random properties, signal
+shapes and packetisations, random property changes / resets between calls, runs it through the C ABI
+and through the oracle, and reports every channel whose four output streams do not match
+(bits / sampleIndex exactly, soft / phase within 1e-5 relative).
+
+usage (GPU box): python tools/fuzz_gpu.py [rounds] [channels] [seed]
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle as po  # noqa: E402
+from psk_soft_amd import lib as pl  # noqa: E402
+
+TOL = 1e-5
+XD = 0.01
+
+
+def make_signal(rng, nrng, M, S, n):
+    n_sym = n // S + 2
+    k = nrng.integers(0, M, n_sym)
+    kind = rng.choice(["shaped", "shaped", "rect", "tri"])
+    j = np.arange(S)
+    if kind == "shaped":
+        pulse = 0.2 + 0.8 * np.sin(np.pi * (j + rng.uniform(0.1, 1.5)) / (S + rng.uniform(0.5, 2.0)))
+    elif kind == "rect":
+        pulse = np.ones(S)
+    else:
+        pulse = 1.0 - np.abs(j - rng.uniform(0, S - 1)) / S
+    amp = 10.0 ** rng.uniform(-3.5, 2.5)
+    cfo = rng.choice([0.0, 1e-3, 1e-2, 0.2]) * rng.uniform(-1, 1) / M
+    ph = 2 * np.pi * k / M + rng.uniform(0, 2 * np.pi)
+    x = np.repeat(np.exp(1j * ph), S) * np.tile(pulse, n_sym)
+    x = x[:n] * np.exp(1j * cfo * np.arange(n) / S) * amp
+    sigma = rng.choice([0.0, 0.003, 0.03, 0.3]) * amp
+    x = x + sigma * (nrng.standard_normal(n) + 1j * nrng.standard_normal(n))
+    if rng.random() < 0.05:  # a silent stretch
+        a = rng.randrange(0, n)
+        x[a : a + rng.randrange(1, 4000)] = 0
+    out = np.empty(2 * n, np.float32)
+    out[0::2] = x.real
+    out[1::2] = x.imag
+    return out
+
+
+def close(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    if a.size != b.size:
+        return False, "size %d vs %d" % (a.size, b.size)
+    fin = np.isfinite(b)
+    if not np.array_equal(np.isfinite(a), fin):
+        return False, "non-finite pattern"
+    if fin.any():
+        err = np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
+        if err > TOL:
+            return False, "rel err %g" % err
+    return True, ""
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    C = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    bad_total = 0
+    for rnd in range(rounds):
+        rng = random.Random(seed * 1000 + rnd)
+        nrng = np.random.default_rng(seed * 1000 + rnd)
+        props, sigs, scripts = [], [], []
+        for c in range(C):
+            S = rng.choice([2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1])
+            A = rng.choice([1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520])
+            M = rng.choice([2, 4, 4, 8])
+            n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400])
+            p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
+            N = max(S * rng.choice([50, 300, 1200, 3000, 12000]), 64)
+            sig = make_signal(rng, nrng, M, max(S, 1), N)
+            # script: a list of events; cuts with occasional tiny / empty packets, property changes, resets
+            n_calls = rng.choice([1, 2, 3, 5])
+            cuts = sorted(rng.sample(range(1, N), min(n_calls - 1, N - 1))) if n_calls > 1 else []
+            ev, prev = [], 0
+            for cut in cuts + [N]:
+                if rng.random() < 0.15:
+                    key = rng.choice(["phaseAvg", "numAvg", "constelationSize", "resetState", "differentialDecoding"])
+                    val = {"phaseAvg": rng.choice([5, 50, 300]), "numAvg": rng.choice([10, 100, 300]),
+                           "constelationSize": rng.choice([2, 4, 8]), "resetState": 1,
+                           "differentialDecoding": rng.choice([0, 1])}[key]
+                    ev.append(("set", key, val))
+                ev.append(("packet", prev, cut, rng.random() < 0.05))
+                prev = cut
+            props.append(p)
+            sigs.append(sig)
+            scripts.append(ev)
+        h = pl.Handle(C, device=0, max_window_samples=16 * 520 + 64, max_phase_avg=512)
+        h.configure(0, props)
+        oracles = []
+        for c in range(C):
+            o = po.OracleComponent()
+            for k, v in props[c].items():
+                setattr(o, k, v)
+            oracles.append(o)
+        got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
+        ref = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
+        pos = [0] * C
+        first = [True] * C
+        # walk the scripts in lock step: one batched call per "tick"
+        while any(pos[c] < len(scripts[c]) for c in range(C)):
+            pk = []
+            for c in range(C):
+                if pos[c] >= len(scripts[c]):
+                    pk.append(None)
+                    continue
+                ev = scripts[c][pos[c]]
+                while ev[0] == "set":
+                    h.configure(c, [{ev[1]: ev[2]}])
+                    setattr(oracles[c], ev[1], ev[2])
+                    pos[c] += 1
+                    ev = scripts[c][pos[c]]
+                a, b, flushed = ev[1], ev[2], ev[3]
+                data = sigs[c][2 * a : 2 * b]
+                pk.append(dict(data=data, xdelta=XD, sriChanged=first[c], inputQueueFlushed=flushed))
+                r = oracles[c].service(data, XD, sriChanged=first[c], inputQueueFlushed=flushed)
+                for k, v in (("soft", r.soft), ("bits", r.bits), ("phase", r.phase), ("index", r.index)):
+                    ref[c][k].append(v)
+                first[c] = False
+                pos[c] += 1
+            res = h.process_host(0, pk)
+            for c in range(C):
+                if pk[c] is not None:
+                    for k in got[c]:
+                        got[c][k].append(res[c][k])
+        st = h.stats()
+        h.close()
+        bad = 0
+        for c in range(C):
+            g = {k: np.concatenate(v) if v else np.zeros(0) for k, v in got[c].items()}
+            r = {k: np.concatenate(v) if v else np.zeros(0) for k, v in ref[c].items()}
+            why = None
+            if not np.array_equal(g["index"], r["index"]):
+                why = "sampleIndex"
+            elif not np.array_equal(g["bits"], r["bits"]):
+                why = "bits (%d differ)" % int((g["bits"] != r["bits"]).sum()) if g["bits"].size == r["bits"].size else "bits size"
+            else:
+                for k in ("soft", "phase"):
+                    ok, msg = close(g[k], r[k])
+                    if not ok:
+                        why = k + " " + msg
+                        break
+            if why:
+                bad += 1
+                print("MISMATCH round %d channel %d: %s  props=%s script=%s" % (rnd, c, why, props[c], scripts[c]))
+        bad_total += bad
+        print("round %d: %d channels, %d mismatches, last-call stats %s" % (rnd, C, bad, st))
+    print("TOTAL mismatches:", bad_total)
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
