@@ -212,7 +212,9 @@ def main():
     achieved = alg_read_bytes / (dev_ms_avg * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tf):
+    # (the PMC traffic figure was collected on the headline configuration only)
+    headline = (M, S, C, N, a.numAvg, a.phaseAvg, a.mixed) == (4, 8, 4096, 1 << 18, 100, 50, False)
+    if headline and os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         except Exception:
