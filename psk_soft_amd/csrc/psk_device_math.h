@@ -194,17 +194,13 @@ PSK_DEV float atan2f_wave(float y, float x)
     bool unused = false;
     return atan2f_wave<false>(y, x, unused, AtanTabWave());
 }
-template <bool LEAN>
-PSK_DEV void sincosf_wave(float t, float *sn, float *cs, bool &special, int dep)
+// sincosf: the straight-line form covers every argument (the large-argument reduction sits behind
+// a wave-uniform test: |theta| >= 120 is ordinary business, the phase estimate grows by the carrier
+// offset times the symbols of the call before the end-of-call wrap brings it back).
+PSK_DEV void sincosf_wave(float t, float *sn, float *cs, int dep)
 {
     bool sp;
     lm_sincosf_ordinary(t, sn, cs, &sp, dep);
-    if (LEAN) {
-        special = special || sp;
-    } else if (__any(sp)) {
-        if (sp)
-            lm_sincosf(t, sn, cs);
-    }
 }
 
 // (long) of a double as x86-64 cvttsd2si does it (cpp/psk_soft.cpp:477, 598)

@@ -747,9 +747,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             if (M == 4)
                 phaseCorrection = (float)((double)phaseCorrection + PSK_KD(kPi4, c));
             float sn, cs;
-            bool sp = false;
-            sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp, c);
-            special = special || (valid[r] && sp);
+            sincosf_wave(phaseCorrection, &sn, &cs, c);
             cf32 ph;
             ph.re = 1.0f * cs;
             ph.im = 1.0f * sn;

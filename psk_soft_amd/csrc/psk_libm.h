@@ -346,8 +346,16 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
     return lm_atan2f_ordinary_t(y, x, special, LmAtanTabHost());
 }
 
-// sinf / cosf for |y| < 120 as one straight line: reduce_fast with n = 0 is the identity for
-// |y| < pi/4, so the two ranges of s_sinf.c share the code; tiny |y| is patched at the end
+// sinf / cosf as one straight line: reduce_fast with n = 0 is the identity for |y| < pi/4, so the
+// first two ranges of s_sinf.c share the code, tiny |y| is patched at the end; for |y| >= 120
+// (ordinary business once a carrier offset has run the phase estimate up) the 192-bit reduction
+// replaces (n, xr) in the lanes that need it, behind a test the whole wave shares.
+// *special is never set any more (kept for the call sites' sake).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PSK_LM_ANY(x) __any(x)
+#else
+#define PSK_LM_ANY(x) (x)
+#endif
 PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, int dep = 0)
 {
     const double HPI_INV = PSK_KD(0x1.45F306DC9C883p+23, dep), HPI = PSK_KD(0x1.921FB54442D18p0, dep);
@@ -357,13 +365,39 @@ PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, in
                  S3 = PSK_KD(-0x1.994eb3774cf24p-13, dep);
     const double C0 = 0x1p0;
     const uint32_t top = lm_abstop12(y);
-    *special = top >= lm_abstop12(120.0f);
+    *special = false;
     const double x = (double)y;
     const double r = x * HPI_INV;
-    const int n = ((int32_t)r + 0x800000) >> 24;
-    const double xr = __builtin_fma(-(double)n, HPI, x);
-    const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;  // sign[n & 3] = {1,-1,-1,1}
-    const double sg = (n & 2) ? -1.0 : 1.0;         // second table entry: cosine coefficients negated
+    int n = ((int32_t)r + 0x800000) >> 24;  // (garbage for huge |y|: replaced below)
+    double xr = __builtin_fma(-(double)n, HPI, x);
+    int q = n;  // selects sign and table entry; the polynomial's parity goes by n
+    const bool big = top >= lm_abstop12(120.0f);
+    if (PSK_LM_ANY(big)) {
+        if (big) {  // reduce_large of sincosf.h: 192 bits of 4/pi; inf / NaN come out as NaN at the end
+            static constexpr uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
+                                                      0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+                                                      0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
+                                                      0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+            uint32_t xi = lm_asuint(y);
+            const int sign = (int)(xi >> 31);
+            const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+            const int shift = (int)((xi >> 23) & 7);
+            xi = (xi & 0xffffff) | 0x800000;
+            xi <<= shift;
+            uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+            uint64_t res1 = (uint64_t)xi * arr[4];
+            uint64_t res2 = (uint64_t)xi * arr[8];
+            res0 = (res2 >> 32) | (res0 << 32);
+            res0 += res1;
+            uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+            res0 -= nn << 62;
+            xr = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+            n = (int)nn;
+            q = n + sign;
+        }
+    }
+    const double sgn = ((q + 1) & 2) ? -1.0 : 1.0;  // sign[q & 3] = {1,-1,-1,1}
+    const double sg = (q & 2) ? -1.0 : 1.0;         // second table entry: cosine coefficients negated
     const double xs = xr * sgn, x2 = xr * xr;
     // sine polynomial
     const double x3 = xs * x2;
@@ -380,8 +414,15 @@ PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, in
     const float pc = (float)__builtin_fma(x6, c2, c);
     const bool odd = (n & 1) != 0;
     const bool tiny = top < lm_abstop12(0x1p-12f);
-    *sp = tiny ? y : (odd ? pc : ps);
-    *cp = tiny ? 1.0f : (odd ? ps : pc);
+    const bool nonfinite = top >= lm_abstop12(__builtin_inff());
+    float sv = tiny ? y : (odd ? pc : ps);
+    float cv = tiny ? 1.0f : (odd ? ps : pc);
+    if (PSK_LM_ANY(nonfinite)) {
+        sv = nonfinite ? y - y : sv;
+        cv = nonfinite ? y - y : cv;
+    }
+    *sp = sv;
+    *cp = cv;
 }
 
 // ---------------------------------------------------------------------------------

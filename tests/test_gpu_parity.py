@@ -569,3 +569,24 @@ def test_opt_in_qpsk_sign_bitmap(oracle_mod, force_seq):
     want[1::2] = ~(im > 0)
     assert np.array_equal(got["bits"], want)
     assert 0.2 < got["bits"].mean() < 0.8
+
+
+def test_large_carrier_offset_in_one_call(oracle_mod):
+    """A carrier offset that runs the phase estimate far beyond 2*pi*M inside ONE call (the wrap only
+    happens at call boundaries, cpp/psk_soft.cpp:592-603): sinf/cosf arguments reach hundreds of
+    radians, i.e. the 192-bit argument reduction of glibc's sincosf, which the screened kernel does
+    in line (stats: no hand-over to the other tiers)."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for M in (2, 4, 8):
+        iq = synth_channel(900 + M, M, 8, 1 << 16, cfo_max=0.6, sigma=0.005)
+        props = dict(samplesPerBaud=8, constelationSize=M)
+        ref = oracle_run(oracle_mod, iq, props)
+        assert np.abs(ref["phase"]).max() > 480.0  # |theta| = |est| / M well above 120
+        h = _handle()
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01)
+        st = h.stats()
+        assert st["channels_fast"] == 1 and st["channels_exact_timing"] == 0 and st["channels_sequential"] == 0, st
+        assert_parity(got, ref, "large CFO M%d" % M)
+        h.close()

@@ -20,7 +20,7 @@ for sec in sys.argv[1:]:
     if sec == "atan":
         swap("rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp, atab);", "rawd[r] = (double)(pw.im + pw.re);")
     elif sec == "sincos":
-        swap("sincosf_wave<LEAN>(phaseCorrection, &sn, &cs, sp, c);", "sn = phaseCorrection; cs = 1.0f - phaseCorrection;")
+        swap("sincosf_wave(phaseCorrection, &sn, &cs, c);", "sn = phaseCorrection; cs = 1.0f - phaseCorrection;")
     elif sec == "pow":
         swap("cf32 pw = cpow_uint<false>(s[r], M);", "cf32 pw = s[r];")
     elif sec == "fit":
