@@ -81,8 +81,11 @@ PSK_DEV cf32 cmul(cf32 x, cf32 y)
     r.re = ac - bd;
     r.im = ad + bc;
     if (RECOVER) {
-        if (is_nan(r.re) && is_nan(r.im))
-            r = cmul_recover(x.re, x.im, y.re, y.im, ac, bd, ad, bc);
+        const bool both_nan = is_nan(r.re) && is_nan(r.im);
+        if (__any(both_nan)) {  // wave-uniform test first: the recovery code stays off the common path
+            if (both_nan)
+                r = cmul_recover(x.re, x.im, y.re, y.im, ac, bd, ad, bc);
+        }
     }
     return r;
 }
@@ -118,7 +121,7 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
     double denom = (cc * cc) + (dd * dd);
     float x = (float)(((aa * cc) + (bb * dd)) / denom);
     float y = (float)(((bb * cc) - (aa * dd)) / denom);
-    if (RECOVER && is_nan(x) && is_nan(y)) {
+    if (RECOVER && __any(is_nan(x) && is_nan(y)) && is_nan(x) && is_nan(y)) {
         if (c == 0.0f && d == 0.0f && (!is_nan(a) || !is_nan(b))) {
             x = __builtin_copysignf(__builtin_inff(), c) * a;
             y = __builtin_copysignf(__builtin_inff(), c) * b;

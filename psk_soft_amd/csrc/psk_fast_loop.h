@@ -25,8 +25,8 @@
 //                  some symbol fails that test is redone exactly on the spot from the LDS ring
 //                  (numAvg <= 128); for larger windows the wave refuses the call (nothing
 //                  committed) and the EXACT = true kernel, launched right behind it, redoes it.
-//                  This instantiation also carries only the straight-line libm forms; the rare
-//                  arguments they do not cover make it refuse the call likewise.
+//                  This instantiation also leaves the general atan2f out; an infinite or NaN
+//                  operand makes it refuse the call likewise.
 //   EXACT = true   the sums are float-valued addends accumulated in double: exact, hence equal
 //                  to the reference's whatever the summation order (quirk Q8), under the
 //                  exponent-spread guard; near-ties resolve by std::max_element's first-maximum
@@ -690,9 +690,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 
         __builtin_amdgcn_s_setprio(0);
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
-        // The screened kernel carries only the straight-line forms of atan2f / sincosf and of the
-        // complex multiply / divide; an argument that needs the general routine (zeros, NaN,
-        // x == 1, ...) makes it refuse the call, and the exact kernel -- which has them -- redoes it.
+        // The screened kernel carries only the straight-line form of atan2f; an infinite or NaN
+        // operand makes it refuse the call, and the exact kernel -- which has the general routine --
+        // redoes it.
         constexpr bool LEAN = !EXACT;
         bool special = false;
         double rawd[kR];
@@ -738,9 +738,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 } else {
                     last = s[0];
                 }
-                smp = cdiv<!LEAN>(s[r], last);
-                if (LEAN)  // __divsc3's recovery branch belongs to the next tier
-                    special = special || (valid[r] && is_nan(smp.re) && is_nan(smp.im));
+                smp = cdiv<true>(s[r], last);  // (__divsc3's recovery behind a wave-uniform test: a silent
+                                               //  stream divides by zero on every symbol)
             } else {
                 phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
             }
@@ -751,9 +750,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             cf32 ph;
             ph.re = 1.0f * cs;
             ph.im = 1.0f * sn;
-            corr[r] = cmul<!LEAN>(smp, ph);
-            if (LEAN)  // (__mulsc3's recovery branch likewise)
-                special = special || (valid[r] && is_nan(corr[r].re) && is_nan(corr[r].im));
+            corr[r] = cmul<true>(smp, ph);
         }
 
         // ---- four output streams, two symbols per lane ----

@@ -263,10 +263,10 @@ PSK_HD void lm_sincosf(float y, float *sp, float *cp)
 }
 
 // ---------------------------------------------------------------------------------
-// Straight-line forms for SIMD execution.  They return the same bits as lm_atan2f /
-// lm_sincosf for every "ordinary" argument and set *special for the rest (atan2f: an infinite or
-// NaN operand; sincosf: |theta| >= 120, inf, NaN): the caller then takes the general routine above.
-// tests/support/libm_pin.cpp checks fast == general wherever *special is false.
+// Straight-line forms for SIMD execution.  lm_atan2f_ordinary returns the same bits as lm_atan2f
+// for every finite operand pair and sets *special for an infinite or NaN operand (the caller then
+// takes the general routine above); lm_sincosf_ordinary covers every argument.
+// tests/support/libm_pin.cpp checks both against glibc wherever *special is false.
 // ---------------------------------------------------------------------------------
 // The five argument ranges of s_atanf.c as one table: with t = (c1*a + c0) / (d1*a + d0) and the
 // result hi - ((t*(s1+s2) - lo) - t), every range -- the first one (t = a, result t - t*(s1+s2))

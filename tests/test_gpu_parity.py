@@ -590,3 +590,28 @@ def test_large_carrier_offset_in_one_call(oracle_mod):
         assert st["channels_fast"] == 1 and st["channels_exact_timing"] == 0 and st["channels_sequential"] == 0, st
         assert_parity(got, ref, "large CFO M%d" % M)
         h.close()
+
+
+def test_silent_streams_stay_on_the_fast_path(oracle_mod):
+    """Idle channels are common in a multichannel system: all-zero packets, and streams with silent
+    gaps, with and without differential decoding (where silence means 0/0 in __divsc3 on every
+    symbol and NaN soft decisions in the reference).  Results as the oracle's, and no hand-over to
+    the slower tiers (one refused channel costs the whole batch a second pass)."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for diff in (0, 1):
+        for kind in ("zeros", "gap"):
+            iq = synth_channel(950 + diff, 4, 8, 1 << 15).copy()
+            if kind == "zeros":
+                iq[:] = 0
+            else:
+                iq[2 * 9000 : 2 * 15000] = 0
+            props = dict(samplesPerBaud=8, constelationSize=4, differentialDecoding=diff)
+            ref = oracle_run(oracle_mod, iq, props, packet=8192)
+            h = _handle()
+            h.configure(0, [props])
+            got = run_gpu(h, 0, iq, 0.01, 8192)
+            st = h.stats()
+            assert_parity(got, ref, "silence diff%d %s" % (diff, kind))
+            assert st["channels_fast"] == 1 and st["channels_sequential"] == 0 and st["channels_exact_timing"] == 0, (st, diff, kind)
+            h.close()
