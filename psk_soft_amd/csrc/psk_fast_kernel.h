@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
     cy.last_k = st->last_k < p.S ? st->last_k : 0u;
     cy.umax = 0u;
     cy.umin1 = 0xFFFFFFFFu;
+    cy.wmax = 0.0f;
+    cy.ambiguous = false;
     cy.refuse = false;
     cy.stat_blocks = 0;
     cy.stat_extra = 0;
@@ -83,13 +85,16 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
         fast_main_loop<SV, HV, EXACT>(p, X, yring, ering, cy);
 
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
-    //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53 ----
+    //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
+    //      for calls in which an exact-timing pass met a best / runner-up pair closer than accumulated
+    //      rounding could explain (cy.ambiguous, psk_fast_loop.h): everywhere else the argmax is the
+    //      reference's whether or not the sums are exact ----
     {
         unsigned umax = wave_max_u32(cy.umax);
         unsigned umin1 = wave_min_u32(cy.umin1);
         if (umax >= 0x7F800000u)
             cy.refuse = true;  // inf / NaN energy
-        if (umin1 != 0xFFFFFFFFu) {
+        if (umin1 != 0xFFFFFFFFu && __any(cy.ambiguous)) {
             int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
             emax = emax < 1 ? 1 : emax;
             emin = emin < 1 ? 1 : emin;

@@ -52,6 +52,10 @@ struct FastCarry {
     uint32_t q;            // number of values ever written to the LDS y ring (history included)
     uint32_t last_k;       // timing index of the last emitted symbol (prediction seed)
     unsigned umax, umin1;  // exactness guard: max energy bits, min (energy bits - 1)
+    float wmax;            // largest window sum seen so far in this call (exact-timing passes)
+    bool ambiguous;        // (per lane) an exact-timing pass found best and runner-up closer than the
+                           // reference's own accumulated rounding could be: only then does the
+                           // exactness guard decide whether the call may stay here
     bool refuse;
     uint32_t stat_blocks, stat_extra, stat_exact_blocks;
 };
@@ -364,6 +368,44 @@ PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int 
     return read_lane(wave_scan_f32(acc), 63);
 }
 
+// Exact-timing bookkeeping shared by the exact kernel and the in-place redo of the screened one.
+// The window sums are float-valued energies accumulated in double.  When their exponent spread is
+// small they are EXACT, in the reference as here, and even a tie resolves identically (first
+// maximum).  When it is not, the reference's accumulators (rebuilt at the top of every call, quirk
+// Q2, then updated twice per symbol, cpp/psk_soft.cpp:572-577) carry rounding errors of at most
+// (updates so far) * 2^-53 * (largest sum so far), and so do ours; the argmax is still provably the
+// reference's wherever best and runner-up differ by more than that.  `ArgTop` tracks both.
+struct ArgTop {
+    double best;
+    float gap;  // best minus the largest other sum so far (rounded to float: only compared with a bound)
+    int k;
+};
+PSK_DEV void argtop_first(ArgTop &t, double W)
+{
+    t.best = W;
+    t.gap = __builtin_inff();
+    t.k = 0;
+}
+PSK_DEV void argtop_next(ArgTop &t, double W, int k)
+{
+    const bool gt = t.best < W;  // std::max_element: first maximum, strict '<' (cpp/psk_soft.cpp:462)
+    const float d = (float)(gt ? W - t.best : t.best - W);
+    // smaller of (gap, d), NaN-propagating: a NaN sum must end up ambiguous
+    const float lo = (d < t.gap || d != d) ? d : t.gap;
+    t.gap = gt ? d : lo;
+    t.best = gt ? W : t.best;
+    t.k = gt ? k : t.k;
+}
+// relative size of the rounding the two sides may have accumulated by output symbol i of the call
+PSK_DEV float drift_bound(int symbols_so_far, uint32_t A)
+{
+    return (float)(4 * symbols_so_far + 2 * (int)A + 2048) * 2.220446e-16f;  // * 2^-52
+}
+PSK_DEV bool argtop_ambiguous(const ArgTop &t, float bound_abs)
+{
+    return !(t.gap > bound_abs);  // (NaN: ambiguous)
+}
+
 // The timing argmax of one block redone exactly from the LDS energy ring (numAvg <= 128), for the
 // screened kernel when its margin test fails somewhere in the block: window sums of float-valued
 // energies accumulated in double (exact under the exponent-spread guard, which is fed here and
@@ -372,15 +414,17 @@ PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int 
 // float, as fresh carries for the screening pass.  `base` = ring offset of the current block.
 template <int S>
 PSK_DEV void exact_block_from_ring(const float *ering, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
-                                   float (&Wf)[S])
+                                   const bool (&valid)[kR], float bound_abs)
 {
     const int prev = base ^ kB;
     const int i_old0 = (base + 2 * lane - (int)A) & (kERing - 1);
     const int i_old1 = (i_old0 + 1) & (kERing - 1);
     const bool in0 = 2 * lane >= kB - (int)A, in1 = 2 * lane + 1 >= kB - (int)A;
-    double bestW[kR] = {0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < S; k++) {  // (unrolled: Wf[] must stay in registers)
+    ArgTop top[kR];
+    argtop_first(top[0], 0.0);
+    argtop_first(top[1], 0.0);
+#pragma unroll 1
+    for (int k = 0; k < S; k++) {  // (a real loop: this path is rare, its registers and code size are not)
         const float *row = ering + k * kERing;
         const float2 en = *reinterpret_cast<const float2 *>(row + base + 2 * lane);
         const float2 ep = *reinterpret_cast<const float2 *>(row + prev + 2 * lane);
@@ -396,15 +440,18 @@ PSK_DEV void exact_block_from_ring(const float *ering, int base, uint32_t A, int
         const double d0 = (double)en.x - (double)eo0, d1 = (double)en.y - (double)eo1;
         const double W1 = Wc + wave_scan_f64(d0 + d1);
         const double W0 = W1 - d1;
-        if (k == 0 || bestW[0] < W0) {  // std::max_element: first maximum, strict '<'
-            bestW[0] = W0;
-            bestK[0] = k;
+        if (k == 0) {
+            argtop_first(top[0], W0);
+            argtop_first(top[1], W1);
+        } else {
+            argtop_next(top[0], W0, k);
+            argtop_next(top[1], W1, k);
         }
-        if (k == 0 || bestW[1] < W1) {
-            bestW[1] = W1;
-            bestK[1] = k;
-        }
-        Wf[k] = uni((float)read_lane(W1, 63));
+    }
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        bestK[r] = top[r].k;
+        cy.ambiguous = cy.ambiguous || (valid[r] && argtop_ambiguous(top[r], bound_abs));
     }
 }
 
@@ -618,10 +665,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             // a near-tie (or a non-finite energy) anywhere: the call goes to the exact kernel
             if (!__all(ok0 && ok1)) {
                 if constexpr (H == 1) {
-                    // settle this block exactly, here; the exact sums also refresh the float carries
-                    exact_block_from_ring<S>(ering, (c & 1) * kB, A, lane, cy, bestK, Wf);
-                    err_c = 2.0f * kU * wmax_prev;
-                    since_refresh = 0;
+                    // settle this block exactly, here.  The float carries stay valid (still within
+                    // their error bound); they are re-summed at the end of this block so that the
+                    // bound, and with it the acceptance threshold, starts small again.
+                    exact_block_from_ring<S>(ering, (c & 1) * kB, A, lane, cy, bestK, valid,
+                                             2.0f * drift_bound(c * kB + kB, A) * wmax_prev);
+                    since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
                 } else {
                     cy.refuse = true;
@@ -630,25 +679,33 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             }
         } else {
             // ---- exact pass: float-valued addends summed in double ----
-            double bestW[kR] = {0.0, 0.0};
+            ArgTop top[kR];
 #pragma unroll
             for (int k = 0; k < S; k++) {
                 // (positions past the end of the call only pollute sums of later positions, which
                 // are past the end too: no masking needed)
                 double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
                 double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
-                double incl = wave_scan_f64(d0 + d1);  // exact (quirk Q8)
+                double incl = wave_scan_f64(d0 + d1);  // exact under the guard (quirk Q8)
                 double W1 = Wc[k] + incl;              // window sum of the lane's second symbol
-                double W0 = W1 - d1;                   // ... and of its first (exact)
+                double W0 = W1 - d1;                   // ... and of its first
                 Wc[k] = read_lane(W1, 63);
-                // std::max_element: first maximum, strict '<' (reference cpp/psk_soft.cpp:462)
-                if (k == 0 || bestW[0] < W0) {
-                    bestW[0] = W0;
-                    bestK[0] = k;
+                if (k == 0) {
+                    argtop_first(top[0], W0);
+                    argtop_first(top[1], W1);
+                } else {
+                    argtop_next(top[0], W0, k);
+                    argtop_next(top[1], W1, k);
                 }
-                if (k == 0 || bestW[1] < W1) {
-                    bestW[1] = W1;
-                    bestK[1] = k;
+            }
+            {
+                const float mx = (float)__builtin_fmax(valid[0] ? top[0].best : 0.0, valid[1] ? top[1].best : 0.0);
+                cy.wmax = __builtin_fmaxf(cy.wmax, wave_max_f32(__builtin_fmaxf(mx, 0.0f)) * 1.0000002f);
+                const float bound_abs = 2.0f * drift_bound(c * kB + kB, A) * cy.wmax;
+#pragma unroll
+                for (int r = 0; r < kR; r++) {
+                    bestK[r] = top[r].k;
+                    cy.ambiguous = cy.ambiguous || (valid[r] && argtop_ambiguous(top[r], bound_abs));
                 }
             }
             cy.stat_exact_blocks += 1;
