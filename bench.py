@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cfo", type=float, default=1e-3,
                     help="carrier offset bound of the stimulus: M*dphi per symbol uniform in [-cfo, cfo] rad (section 8(d): 1e-3)")
     ap.add_argument("--sigma", type=float, default=0.01, help="noise per component of the stimulus (section 8(d): 0.01)")
+    ap.add_argument("--scale", type=float, default=1.0, help="amplitude factor applied to the whole stimulus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall seconds of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a few channels against the oracle after the run")
@@ -150,6 +151,8 @@ def main():
             iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=0x5EED0000 + rank * 3 + j, cfo_max=a.cfo, sigma=a.sigma)
     else:
         iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank, cfo_max=a.cfo, sigma=a.sigma)
+    if a.scale != 1.0:
+        iq *= a.scale
     # output rows start on 128-byte boundaries in all four streams (64 symbols of the narrowest one):
     # rows that straddle cache lines cost 8 % of the streaming ceiling (tools/micro/placement_probe.hip)
     cap = (N // S + 2 + 63) // 64 * 64

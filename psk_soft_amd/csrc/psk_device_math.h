@@ -153,10 +153,11 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
 // in the first five lanes of one VGPR and an entry is fetched with ds_bpermute -- one LDS-crossbar
 // instruction instead of a chain of selects, and fewer registers than the broadcast constants.
 struct AtanTabDev {
-    int row[6];
+    int packed;  // lane 5*which + id holds T[which][id]: all six rows in one register
     PSK_DEV float get(int which, int id) const
     {
-        return __int_as_float(__builtin_amdgcn_ds_bpermute(id << 2, row[which]));
+        // (the row offset folds into the instruction's offset field)
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((id << 2) + 20 * which, packed));
     }
     PSK_DEV static bool any(bool v) { return __any(v); }
 };
@@ -164,16 +165,15 @@ PSK_DEV AtanTabDev atan_tab_dev(int lane)
 {
     AtanTabDev t;
     const LmAtanTabHost h;
+    float v = 0.0f;
 #pragma unroll
-    for (int which = 0; which < 6; which++) {
-        float v = 0.0f;
+    for (int which = 0; which < 6; which++)
 #pragma unroll
-        for (int id = 0; id < 5; id++) v = (lane == id) ? h.get(which, id) : v;
-        t.row[which] = __float_as_int(v);
-    }
+        for (int id = 0; id < 5; id++) v = (lane == 5 * which + id) ? h.get(which, id) : v;
+    t.packed = __float_as_int(v);
     return t;
 }
-// (every lane of the wave must be active where the table form is used: ds_bpermute reads lanes 0-4)
+// (every lane of the wave must be active where the table form is used: ds_bpermute reads lanes 0-29)
 struct AtanTabWave {
     PSK_DEV float get(int which, int id) const { return LmAtanTabHost().get(which, id); }
     PSK_DEV static bool any(bool v) { return __any(v); }
@@ -295,9 +295,10 @@ PSK_DEV FitKnown fit_known(float xdelta, unsigned pts, float denominator, float 
     k.rpts = uni(1.0 / (double)pts);
     return k;
 }
-PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k)
+PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k, float &m_out)
 {
     float m = (float)lm_div_known(xySum - k.half_span_d * ySum, k.den_d, k.rden);
+    m_out = m;
     float mx = m * k.xavg;
     float b = (float)(lm_div_known(ySum, k.pts_d, k.rpts) - (double)mx);
     float mxv = m * k.xval;

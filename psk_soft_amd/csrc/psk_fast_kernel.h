@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
     cy.last_im = st->last_im;
     cy.den = st->lf_den;
     cy.xavg = st->lf_xavg;
+    cy.slope = is_fin(st->lf_m) ? st->lf_m : 0.0f;  // (a hint only: the slope of the last fit, per symbol)
     cy.q = len0;
     cy.last_k = st->last_k < p.S ? st->last_k : 0u;
     cy.umax = 0u;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
             st->phaseEstimate = pe;
             st->lf_den = cy.den;
             st->lf_xavg = cy.xavg;
+            st->lf_m = cy.slope;
             st->guard = EXACT ? 3u : 0u;
             st->last_k = cy.last_k;
             st->stat_blocks = cy.stat_blocks;

@@ -49,6 +49,7 @@ struct FastCarry {
     float last_re, last_im;
     float den, xavg;       // LinearFit::denominator / xAvg
     float m, b;            // scratch for the prologue / epilogue fits
+    float slope;           // slope of the last fit, per symbol: predicts the estimates of the next block
     uint32_t q;            // number of values ever written to the LDS y ring (history included)
     uint32_t last_k;       // timing index of the last emitted symbol (prediction seed)
     unsigned umax, umin1;  // exactness guard: max energy bits, min (energy bits - 1)
@@ -248,18 +249,20 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             xavg_l[r] = xavg_s;
         }
     }
-    // speculate numWraps by consecutive differences (position 0: against the carried estimate)
+    // Speculate numWraps from a PREDICTION of the feedback: the estimate fed back at position s of
+    // the block is, to first order, the carried estimate continued along the last fitted line
+    // (cpp/psk_soft.cpp:477 with est[s-1] ~ est_carry + slope*s).  Every position guesses on its
+    // own, so a noisy sample spoils one guess, not all that follow (guessing by consecutive raw
+    // differences did: at 10 dB it needed 9 correction passes a block).  Position 0 is exact.
     int w[kR];
     {
         // (a guess only: float arithmetic is enough; every count is verified below)
-        const float rf0 = (float)rawd[0], rf1 = (float)rawd[1];
         const float inv2pi = 0.15915494f;
-        const float rprev = wave_up1(rf1, cy.est);  // lane 0: the carried estimate
-        int dl0 = (int)__builtin_rintf((rprev - rf0) * inv2pi);
-        int dl1 = (int)__builtin_rintf((rf0 - rf1) * inv2pi);
-        int incl = wave_scan_i32(dl0 + dl1);
-        w[1] = incl;
-        w[0] = incl - dl1;
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            const float pred = cy.est + cy.slope * (float)(2 * lane + r);
+            w[r] = (int)__builtin_rintf((pred - (float)rawd[r]) * inv2pi);
+        }
     }
     const double two_pi = PSK_KD(kTwoPi, (int)q0);
     int pass = 0;
@@ -298,9 +301,9 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         xySum_l[1] = xySum_l[0] + c1;
 #pragma unroll
         for (int r = 0; r < kR; r++) {
-            float m_, b_;
+            float m_ = 0.0f, b_;
             if (!WARM) {  // steady state: both divisors are wave-uniform
-                est[r] = fit_value_known(ySum_l[r], xySum_l[r], fk);
+                est[r] = fit_value_known(ySum_l[r], xySum_l[r], fk, m_);
             } else if (pts[r] > 1) {
                 est[r] = fit_value(ySum_l[r], xySum_l[r], xd, pts[r], den_l[r], xavg_l[r], m_, b_);
             } else {  // :164-171, a single point: b = yvals.back()
@@ -889,6 +892,14 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             cy.ySum = read_lane(ys, lane_last);
             cy.xySum = read_lane(xys, lane_last);
             cy.est = read_lane(e_, lane_last);
+            {
+                // slope of the line just fitted, per symbol (LinearFit::m * xdelta, steady-state
+                // constants): only a hint for the next block's speculation, so approximate is fine
+                float m_hint;
+                (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
+                m_hint *= xd;
+                cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
+            }
             if (p.diff) {  // `last` only moves while differentialDecoding is on (cpp/psk_soft.cpp:486-491)
                 cy.last_re = read_lane(sre, lane_last);
                 cy.last_im = read_lane(sim, lane_last);
