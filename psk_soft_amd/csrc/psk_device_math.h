@@ -309,7 +309,14 @@ PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k, floa
 // the default, bit-exact with the reference); sign_map = the mapping of the diagram at :516-521
 PSK_DEV void qpsk_bits(float re, float im, bool sign_map, int &b0, int &b1)
 {
-    const int r = sign_map ? (re > 0.0f) : (re != 0.0f), m = sign_map ? (im > 0.0f) : (im != 0.0f);
+    int r, m;
+    if (sign_map) {  // (wave-uniform: a scalar branch, one of the two pairs of compares is executed)
+        r = re > 0.0f;
+        m = im > 0.0f;
+    } else {
+        r = re != 0.0f;
+        m = im != 0.0f;
+    }
     b0 = r ^ m;
     b1 = !m;
 }
