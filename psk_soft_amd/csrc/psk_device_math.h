@@ -334,9 +334,9 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
     return (float)asInt > wrapValue;
 }
 
-// 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17)
+// 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17) by the reference's own expression
 template <bool LEAN, class Tab>
-PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special, const Tab &tab)
+PSK_DEV unsigned short slice_8psk_atan(float c_re, float c_im, bool &special, const Tab &tab)
 {
     float theta = atan2f_wave<LEAN>(c_im, c_re, special, tab);
     float softsym = (float)((double)theta / kPi * 4);
@@ -349,6 +349,22 @@ PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special, const T
     else
         asInt = (int)r;
     return (unsigned short)(unsigned)asInt;
+}
+// ... and as the kernels compute it: the sector from two compares (lm_slice8_fast), the arctangent
+// only when some lane's point lies next to a decision boundary.  The whole wave then runs it (its
+// range table lives in lanes), the lanes concerned take its answer.
+template <bool LEAN, class Tab>
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special, const Tab &tab)
+{
+    bool nearb;
+    unsigned s = lm_slice8_fast(c_re, c_im, &nearb);
+    if (__any(nearb)) {
+        bool sp = false;
+        const unsigned full = slice_8psk_atan<LEAN>(c_re, c_im, sp, tab);
+        s = nearb ? full : s;
+        special = special || (nearb && sp);
+    }
+    return (unsigned short)s;
 }
 
 PSK_DEV unsigned short slice_8psk(float c_re, float c_im)

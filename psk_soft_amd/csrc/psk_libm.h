@@ -426,6 +426,34 @@ PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, in
 }
 
 // ---------------------------------------------------------------------------------
+// 8-PSK sector of a point without the arctangent.  The reference slices by
+// round(atan2f(im, re) / pi * 4) (cpp/psk_soft.cpp:547-555): the decision boundaries are the rays at
+// odd multiples of pi/8, i.e. |im| = tan(pi/8) |re| and |im| = tan(3 pi/8) |re|.  Away from them the
+// sector follows from two compares and the signs; *near is set where the point lies within 4e-5
+// (relative) of a boundary, is the origin, or is not finite -- there the caller takes the
+// arctangent, whose last-bit behaviour decides.  (atan2f is good to an ulp and the float / double
+// steps after it to 2^-24: seven hundred times finer than the margin.)
+// tests/support/libm_pin.cpp checks the result against the reference expression wherever !*near.
+// ---------------------------------------------------------------------------------
+PSK_HD unsigned lm_slice8_fast(float re, float im, bool *near)
+{
+    const float T1 = 0.41421356f, T3 = 2.41421356f, eps = 4.0e-5f;
+    const float u = __builtin_fabsf(re), t = __builtin_fabsf(im);
+    const float a1 = T1 * u, a3 = T3 * u;
+    const bool lo = t < a1, hi = t > a3;
+    const bool neg_re = lm_asuint(re) >> 31, neg_im = lm_asuint(im) >> 31;
+    // sectors: 0 around +re, 2 around +im, 4 around -re, 6 around -im, odd ones in between
+    const unsigned diag = neg_re ? (neg_im ? 5u : 3u) : (neg_im ? 7u : 1u);
+    const unsigned axis_re = neg_re ? 4u : 0u, axis_im = neg_im ? 6u : 2u;
+    const unsigned s = lo ? axis_re : (hi ? axis_im : diag);
+    const float d1 = __builtin_fabsf(t - a1), d3 = __builtin_fabsf(t - a3);
+    const bool fin = (lm_asuint(u) < 0x7f800000u) && (lm_asuint(t) < 0x7f800000u);
+    // (!(x > y) rather than x <= y: a NaN anywhere lands in *near)
+    *near = !fin || !(d1 > eps * (t + a1)) || !(d3 > eps * (t + a3));
+    return s;
+}
+
+// ---------------------------------------------------------------------------------
 // a / b for a divisor whose correctly rounded reciprocal rb = 1.0 / b is known
 // (Markstein: q = RN(a*rb), r = a - q*b exactly by fma, RN(q + r*rb) is the correctly
 // rounded quotient; the excluded case, a divisor significand of all ones, cannot occur for

@@ -82,6 +82,29 @@ int main(int argc, char **argv)
         double a = (unit() - 0.5) * ldexp(1.0, (int)(rnd() % 80) - 40);
         if (psk::lm_div_known(a, b, 1.0 / b) != a / b) bad_d++;
     }
+    // 8-PSK sector without the arctangent vs the reference expression (cpp/psk_soft.cpp:547-555)
+    long bad_s8 = 0, n_near = 0;
+    for (long i = 0; i < n_each; i++) {
+        float re, im;
+        switch (i % 4) {
+        case 0: re = (float)(unit() * 4 - 2); im = (float)(unit() * 4 - 2); break;
+        case 1: { double a = unit() * 6.283185307179586, r = ldexp(1.0, (int)(rnd() % 60) - 30);  // all angles, many scales
+                  re = (float)(r * cos(a)); im = (float)(r * sin(a)); break; }
+        case 2: { int k = (int)(rnd() % 16); double a = k * 0.39269908169872414 + (unit() - 0.5) * 1e-3;  // around the rays
+                  re = (float)cos(a); im = (float)sin(a); break; }
+        default: re = anyf(); im = anyf(); break;
+        }
+        bool nearb;
+        unsigned fast = psk::lm_slice8_fast(re, im, &nearb);
+        if (nearb) { n_near++; continue; }
+        float theta = atan2f(im, re);
+        float softsym = (float)((double)theta / M_PI * 4);
+        if ((double)softsym < -.5) softsym = softsym + 8.0f;
+        unsigned short sym = (unsigned short)round((double)softsym);
+        if (sym != fast) bad_s8++;
+    }
+    printf("slice8: bad=%ld (near a boundary, left to atan2f: %ld of %ld)\n", bad_s8, n_near, n_each);
+    if (bad_s8) return 1;
     printf("n=%ld sinf_bad=%ld cosf_bad=%ld atan2f_bad=%ld atanf_bad=%ld div_bad=%ld\n", n_each, bad_s, bad_c, bad_a2, bad_a, bad_d);
     printf("ordinary forms: sincos_bad=%ld (special %ld) atan2_bad=%ld (special %ld)\n", bad_fs, n_sp_s, bad_fa, n_sp_a);
     return (bad_s || bad_c || bad_a2 || bad_a || bad_d || bad_fs || bad_fa) ? 1 : 0;
