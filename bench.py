@@ -148,9 +148,9 @@ def main():
         iq = torch.empty((C, 2 * N), dtype=torch.float32, device=dev)
         for j, Mj in enumerate((2, 4, 8)):
             idx = torch.arange(j, C, 3, device=dev)
-            iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=0x5EED0000 + rank * 3 + j, cfo_max=a.cfo, sigma=a.sigma)
+            iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=0x5EED0000 + rank * 3 + j, cfo_max=a.cfo, sigma=a.sigma, periodic=True)
     else:
-        iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank, cfo_max=a.cfo, sigma=a.sigma)
+        iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank, cfo_max=a.cfo, sigma=a.sigma, periodic=True)
     if a.scale != 1.0:
         iq *= a.scale
     # output rows start on 128-byte boundaries in all four streams (64 symbols of the narrowest one):

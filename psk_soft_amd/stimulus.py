@@ -92,9 +92,12 @@ def synth_channels(channels, M, S, n_complex, **kw):
 
 
 def synth_channels_torch(n_channels, M, S, n_complex, device, sigma=0.01, cfo_max=1e-3, seed=SEED_BASE,
-                         chunk_channels=256):
+                         chunk_channels=256, periodic=False):
     """Same workload, generated on the GPU with torch ops (bench sizes: GiBs of I/Q).
-    Returns a [n_channels, 2*n_complex] float32 tensor on `device`."""
+    Returns a [n_channels, 2*n_complex] float32 tensor on `device`.
+    periodic=True rounds every channel's carrier offset to the nearest value whose phase advance over
+    the buffer is a multiple of 2*pi/M, so that feeding the same buffer again and again (as bench.py
+    does) is one continuous stream for the carrier loop instead of a phase jump per call."""
     import torch
 
     gen = torch.Generator(device=device)
@@ -109,6 +112,9 @@ def synth_channels_torch(n_channels, M, S, n_complex, device, sigma=0.01, cfo_ma
         phi0 = torch.rand((nc, 1), generator=gen, device=device) * (2 * math.pi / M)
         gain = 0.5 + 1.5 * torch.rand((nc, 1), generator=gen, device=device)
         dphi = (2 * torch.rand((nc, 1), generator=gen, device=device) - 1) * (cfo_max / M)
+        if periodic and n_complex % S == 0:
+            q = 2 * math.pi / (M * n_sym)
+            dphi = torch.round(dphi / q) * q
         tsym = torch.arange(n_sym, device=device, dtype=torch.float32).unsqueeze(0)
         sym_phase = k.to(torch.float32) * (2 * math.pi / M) + phi0 + dphi * tsym
         # CFO ramp inside a symbol is < 1e-3/M rad: applied per symbol (documented approximation)
