@@ -313,13 +313,17 @@ namespace psk {
 #define PSK_DECL_SH(S, H) PSK_DECL(S, H, 0) PSK_DECL(S, H, 1)
 #define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S(2)
+PSK_DECL_S(3)
 PSK_DECL_S(4)
 PSK_DECL_S(5)
+PSK_DECL_S(6)
+PSK_DECL_S(7)
 PSK_DECL_S(8)
 PSK_DECL_S(10)
+PSK_DECL_S(12)
 PSK_DECL_S(16)
 
-// S = 0: the channels that emit nothing this call.  Otherwise S in {2,4,5,8,10,16}, H in {1,2,4}
+// S = 0: the channels that emit nothing this call.  Otherwise S in {2,3,4,5,6,7,8,10,12,16}, H in {1,2,4}
 // blocks of window history, exact = 0 (screened timing) / 1 (exact timing, runs on refused calls).
 hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
 {
@@ -331,10 +335,14 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
                      : launch_fast_S##Sv##_H##Hv##_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
 #define PSK_CASE_S(Sv) PSK_CASE(Sv, 1) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S(2)
+    PSK_CASE_S(3)
     PSK_CASE_S(4)
     PSK_CASE_S(5)
+    PSK_CASE_S(6)
+    PSK_CASE_S(7)
     PSK_CASE_S(8)
     PSK_CASE_S(10)
+    PSK_CASE_S(12)
     PSK_CASE_S(16)
     return hipErrorInvalidValue;
 }
