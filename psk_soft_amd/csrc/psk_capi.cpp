@@ -418,7 +418,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // reference-order kernel (below) the calls both refused
     for (int exact = 0; exact <= 1; exact++)
         for (int S : kFastS)
-            for (int H = 1; H <= 4; H++)
+            for (int H = exact ? 2 : 1; H <= 4; H++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
                 if (need_SH[S][H])
                     PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
                                              h->lim.ring_cap, h->d_yv, h->lim.fit_cap, stream));

@@ -179,16 +179,18 @@ struct AtanTabWave {
     PSK_DEV static bool any(bool v) { return __any(v); }
 };
 
+// atan2f for a whole wave: the table-driven straight line for every finite operand pair, a few
+// constants for a NaN or an infinity (wave-uniform test first: practically never taken).  `special`
+// is kept in the signature and never set any more: no kernel needs another tier for atan2f.
 template <bool LEAN, class Tab>
 PSK_DEV float atan2f_wave(float y, float x, bool &special, const Tab &tab)
 {
+    (void)special;
     bool sp;
     float r = lm_atan2f_ordinary_t(y, x, &sp, tab);
-    if (LEAN) {
-        special = special || sp;
-    } else if (__any(sp)) {
+    if (__any(sp)) {
         if (sp)
-            r = lm_atan2f(y, x);
+            r = lm_atan2f_nonfinite(y, x);
     }
     return r;
 }
@@ -338,6 +340,8 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 template <bool LEAN, class Tab>
 PSK_DEV unsigned short slice_8psk_atan(float c_re, float c_im, bool &special, const Tab &tab)
 {
+    // (NaN arrives here as a matter of course: the first symbol of every differentially decoded
+    // stream divides by last = 0, cpp/psk_soft.cpp:486-491)
     float theta = atan2f_wave<LEAN>(c_im, c_re, special, tab);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)

@@ -25,8 +25,7 @@
 //                  some symbol fails that test is redone exactly on the spot from the LDS ring
 //                  (numAvg <= 128); for larger windows the wave refuses the call (nothing
 //                  committed) and the EXACT = true kernel, launched right behind it, redoes it.
-//                  This instantiation also leaves the general atan2f out; an infinite or NaN
-//                  operand makes it refuse the call likewise.
+//                  For numAvg <= 128 there is no EXACT = true instantiation at all.
 //   EXACT = true   the sums are float-valued addends accumulated in double: exact, hence equal
 //                  to the reference's whatever the summation order (quirk Q8), under the
 //                  exponent-spread guard; near-ties resolve by std::max_element's first-maximum
@@ -750,9 +749,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 
         __builtin_amdgcn_s_setprio(0);
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
-        // The screened kernel carries only the straight-line form of atan2f; an infinite or NaN
-        // operand makes it refuse the call, and the exact kernel -- which has the general routine --
-        // redoes it.
+        // (`special` is a leftover of the days when rare libm arguments were handed to another
+        // kernel; every routine now covers all its arguments and never sets it)
         constexpr bool LEAN = !EXACT;
         bool special = false;
         double rawd[kR];

@@ -311,7 +311,10 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
 namespace psk {
 #define PSK_DECL(S, H, E) hipError_t launch_fast_S##S##_H##H##_E##E(PSK_FAST_ARGS);
 #define PSK_DECL_SH(S, H) PSK_DECL(S, H, 0) PSK_DECL(S, H, 1)
-#define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
+// (numAvg <= 128 has no exact-timing instantiation: its screened kernel settles near-ties itself, and
+// whatever else makes it refuse a call -- non-finite data, the exactness guard -- the exact kernel
+// would refuse too; those calls go straight to the reference-order kernel)
+#define PSK_DECL_S(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S(2)
 PSK_DECL_S(3)
 PSK_DECL_S(4)
@@ -333,7 +336,11 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     if (S == Sv && H == Hv)                                                                                           \
         return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream) \
                      : launch_fast_S##Sv##_H##Hv##_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
-#define PSK_CASE_S(Sv) PSK_CASE(Sv, 1) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
+#define PSK_CASE1(Sv)                                                                                                 \
+    if (S == Sv && H == 1)                                                                                            \
+        return exact ? hipSuccess                                                                                     \
+                     : launch_fast_S##Sv##_H1_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
+#define PSK_CASE_S(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S(2)
     PSK_CASE_S(3)
     PSK_CASE_S(4)

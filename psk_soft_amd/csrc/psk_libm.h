@@ -346,6 +346,24 @@ PSK_HD float lm_atan2f_ordinary(float y, float x, bool *special)
     return lm_atan2f_ordinary_t(y, x, special, LmAtanTabHost());
 }
 
+// atan2f for the operand pairs lm_atan2f_ordinary_t leaves out (*special): a NaN or an infinity
+// somewhere.  The handful of constants of e_atan2f.c, nothing else.
+PSK_HD float lm_atan2f_nonfinite(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f;
+    const uint32_t ux = lm_asuint(x), uy = lm_asuint(y);
+    const uint32_t ix = ux & 0x7fffffffu, iy = uy & 0x7fffffffu;
+    const bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
+    if (ix > 0x7f800000u || iy > 0x7f800000u)
+        return x + y;  // NaN
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u)
+            return xneg ? (yneg ? -3.0f * pi_o_4 - tiny : 3.0f * pi_o_4 + tiny) : (yneg ? -pi_o_4 - tiny : pi_o_4 + tiny);
+        return xneg ? (yneg ? -pi - tiny : pi + tiny) : (yneg ? -0.0f : 0.0f);
+    }
+    return yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;  // y infinite, x finite
+}
+
 // sinf / cosf as one straight line: reduce_fast with n = 0 is the identity for |y| < pi/4, so the
 // first two ranges of s_sinf.c share the code, tiny |y| is patched at the end; for |y| >= 120
 // (ordinary business once a carrier offset has run the phase estimate up) the 192-bit reduction

@@ -69,8 +69,10 @@ int main(int argc, char **argv)
         if (!same(psk::lm_atanf(y), atanf(y))) bad_a++;
         bool sp;
         float fa = psk::lm_atan2f_ordinary(y, x, &sp);
-        if (sp) n_sp_a++;
-        else if (!same(fa, atan2f(y, x))) bad_fa++;
+        if (sp) {
+            n_sp_a++;
+            if (!same(psk::lm_atan2f_nonfinite(y, x), atan2f(y, x))) bad_fa++;
+        } else if (!same(fa, atan2f(y, x))) bad_fa++;
     }
     for (long i = 0; i < n_each; i++) {
         double b;
