@@ -143,12 +143,8 @@ PSK_DEV cf32 cdiv(cf32 n, cf32 dn)
     return r;
 }
 
-// atan2f / sincosf for a whole wave: the straight-line form, and the general routine only if
-// some lane holds a special argument (wave-uniform branch, practically never taken)
-//
-// LEAN = true leaves the general routine out of the instruction stream altogether: a special
-// argument is only reported (special |= ...) and the caller hands the whole call to the next
-// kernel tier, which has the general routine.
+// atan2f / sincosf for a whole wave: straight-line forms that cover every argument, the rare ones
+// (NaN, infinities, huge angles) behind wave-uniform tests that are practically never taken.
 // The range table of the straight-line atan2f (LmAtanTabHost) held in registers: row `which` lives
 // in the first five lanes of one VGPR and an entry is fetched with ds_bpermute -- one LDS-crossbar
 // instruction instead of a chain of selects, and fewer registers than the broadcast constants.
@@ -180,12 +176,10 @@ struct AtanTabWave {
 };
 
 // atan2f for a whole wave: the table-driven straight line for every finite operand pair, a few
-// constants for a NaN or an infinity (wave-uniform test first: practically never taken).  `special`
-// is kept in the signature and never set any more: no kernel needs another tier for atan2f.
-template <bool LEAN, class Tab>
-PSK_DEV float atan2f_wave(float y, float x, bool &special, const Tab &tab)
+// constants for a NaN or an infinity (wave-uniform test first: practically never taken)
+template <class Tab>
+PSK_DEV float atan2f_wave(float y, float x, const Tab &tab)
 {
-    (void)special;
     bool sp;
     float r = lm_atan2f_ordinary_t(y, x, &sp, tab);
     if (__any(sp)) {
@@ -194,11 +188,7 @@ PSK_DEV float atan2f_wave(float y, float x, bool &special, const Tab &tab)
     }
     return r;
 }
-PSK_DEV float atan2f_wave(float y, float x)
-{
-    bool unused = false;
-    return atan2f_wave<false>(y, x, unused, AtanTabWave());
-}
+PSK_DEV float atan2f_wave(float y, float x) { return atan2f_wave(y, x, AtanTabWave()); }
 // sincosf: the straight-line form covers every argument (the large-argument reduction sits behind
 // a wave-uniform test: |theta| >= 120 is ordinary business, the phase estimate grows by the carrier
 // offset times the symbols of the call before the end-of-call wrap brings it back).
@@ -337,12 +327,12 @@ PSK_DEV bool wrap_test(float phaseEstimate, float wrapValue)
 }
 
 // 8-PSK symbol index (cpp/psk_soft.cpp:547-555, quirk Q17) by the reference's own expression
-template <bool LEAN, class Tab>
-PSK_DEV unsigned short slice_8psk_atan(float c_re, float c_im, bool &special, const Tab &tab)
+template <class Tab>
+PSK_DEV unsigned short slice_8psk_atan(float c_re, float c_im, const Tab &tab)
 {
     // (NaN arrives here as a matter of course: the first symbol of every differentially decoded
     // stream divides by last = 0, cpp/psk_soft.cpp:486-491)
-    float theta = atan2f_wave<LEAN>(c_im, c_re, special, tab);
+    float theta = atan2f_wave(c_im, c_re, tab);
     float softsym = (float)((double)theta / kPi * 4);
     if ((double)softsym < -.5)
         softsym = softsym + 8.0f;
@@ -357,25 +347,19 @@ PSK_DEV unsigned short slice_8psk_atan(float c_re, float c_im, bool &special, co
 // ... and as the kernels compute it: the sector from two compares (lm_slice8_fast), the arctangent
 // only when some lane's point lies next to a decision boundary.  The whole wave then runs it (its
 // range table lives in lanes), the lanes concerned take its answer.
-template <bool LEAN, class Tab>
-PSK_DEV unsigned short slice_8psk(float c_re, float c_im, bool &special, const Tab &tab)
+template <class Tab>
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im, const Tab &tab)
 {
     bool nearb;
     unsigned s = lm_slice8_fast(c_re, c_im, &nearb);
     if (__any(nearb)) {
-        bool sp = false;
-        const unsigned full = slice_8psk_atan<LEAN>(c_re, c_im, sp, tab);
+        const unsigned full = slice_8psk_atan(c_re, c_im, tab);
         s = nearb ? full : s;
-        special = special || (nearb && sp);
     }
     return (unsigned short)s;
 }
 
-PSK_DEV unsigned short slice_8psk(float c_re, float c_im)
-{
-    bool unused = false;
-    return slice_8psk<false>(c_re, c_im, unused, AtanTabWave());
-}
+PSK_DEV unsigned short slice_8psk(float c_re, float c_im) { return slice_8psk(c_re, c_im, AtanTabWave()); }
 
 }  // namespace psk
 #endif

@@ -749,19 +749,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 
         __builtin_amdgcn_s_setprio(0);
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
-        // (`special` is a leftover of the days when rare libm arguments were handed to another
-        // kernel; every routine now covers all its arguments and never sets it)
-        constexpr bool LEAN = !EXACT;
-        bool special = false;
         double rawd[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             cf32 pw = cpow_uint<false>(s[r], M);
             if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
                 cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-            bool sp = false;
-            rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp, atab);
-            special = special || (valid[r] && sp);
+            rawd[r] = (double)atan2f_wave(pw.im, pw.re, atab);
         }
 
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
@@ -816,9 +810,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         if (p.bits && p.bpb == 3) {  // 8-PSK slicing with the whole wave active (the atan2f table lives in lanes 0-4)
 #pragma unroll
             for (int r = 0; r < kR; r++) {
-                bool sp = false;
-                sym8[r] = slice_8psk<LEAN>(corr[r].re, corr[r].im, sp, atab);
-                special = special || (valid[r] && sp);
+                sym8[r] = slice_8psk(corr[r].re, corr[r].im, atab);
             }
         }
         if (valid[1]) {
@@ -873,11 +865,6 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 p.bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
                 p.bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
             }
-        }
-
-        if (LEAN && __any(special)) {
-            cy.refuse = true;
-            return;
         }
 
         // ---- carries into the next block: the last valid position of this one ----

@@ -18,7 +18,7 @@ def swap(old, new):
 
 for sec in sys.argv[1:]:
     if sec == "atan":
-        swap("rawd[r] = (double)atan2f_wave<LEAN>(pw.im, pw.re, sp, atab);", "rawd[r] = (double)(pw.im + pw.re);")
+        swap("rawd[r] = (double)atan2f_wave(pw.im, pw.re, atab);", "rawd[r] = (double)(pw.im + pw.re);")
     elif sec == "sincos":
         swap("sincosf_wave(phaseCorrection, &sn, &cs, c);", "sn = phaseCorrection; cs = 1.0f - phaseCorrection;")
     elif sec == "pow":
