@@ -802,7 +802,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
             cf32 ph;
             ph.re = 1.0f * cs;
             ph.im = 1.0f * sn;
-            corr[r] = cmul<true>(smp, ph);
+            // (__mulsc3's recovery only ever changes a product with an infinite factor: impossible
+            // without differential decoding, where smp is a sample whose M-th power was finite)
+            corr[r] = p.diff ? cmul<true>(smp, ph) : cmul<false>(smp, ph);
         }
 
         // ---- four output streams, two symbols per lane ----
