@@ -615,3 +615,19 @@ def test_silent_streams_stay_on_the_fast_path(oracle_mod):
             assert_parity(got, ref, "silence diff%d %s" % (diff, kind))
             assert st["channels_fast"] == 1 and st["channels_sequential"] == 0 and st["channels_exact_timing"] == 0, (st, diff, kind)
             h.close()
+
+
+def test_randomised_streams(oracle_mod, monkeypatch):
+    """Three rounds of tools/fuzz_gpu.py (fixed seeds): random properties -- including values only the
+    reference-order kernel takes --, amplitudes over six decades, noise from none to -10 dB SNR,
+    rectangular / triangular / shaped pulses, silent stretches, carrier offsets that wrap, ragged
+    packets, property changes, resets and flushed queues between calls; every channel against the
+    oracle.  (Longer runs of the same tool: DESIGN.md section 4.)"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu
+
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "3", "160", "7"])
+    assert fuzz_gpu.main() == 0
