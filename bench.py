@@ -30,7 +30,8 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps; the first ~8 launches of a process run 2-8 %% slower (clock ramp), see DESIGN.md")
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--nsamp", type=int, default=1 << 18, help="complex samples per channel per step")
     ap.add_argument("--M", type=int, default=4)
