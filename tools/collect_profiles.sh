@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 20 --warmup 3 --check > $out/bench.json 2> $out/bench.err
+python3 $R/bench.py --steps 20 --warmup 10 --check > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_write -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $out/pmc_write.log 2>&1
