@@ -124,3 +124,20 @@ def test_create_without_gpu_fails_loudly():
     with pytest.raises(pl.PskSoftError) as e:
         pl.Handle(1, device=0)
     assert e.value.status == 2  # PSK_SOFT_ERR_NO_DEVICE: no silent CPU path
+
+
+def test_options_and_pinned_allocation_without_gpu():
+    """psk_soft_set_option is control-plane state (works on a control-plane-only handle, rejects
+    unknown options); psk_soft_host_alloc needs the HIP runtime and must fail loudly without it."""
+    import torch
+
+    h = pl.Handle(1, device=pl.DEVICE_NONE) if hasattr(pl, "DEVICE_NONE") else pl.Handle(1, device=-1)
+    h.set_option(h.OPT_QPSK_SIGN_BITMAP, 1)
+    h.set_option(h.OPT_QPSK_SIGN_BITMAP, 0)
+    with pytest.raises(pl.PskSoftError) as e:
+        h.set_option(12345, 1)
+    assert e.value.status == 1  # PSK_SOFT_ERR_INVALID_ARG
+    h.close()
+    if not torch.cuda.is_available():
+        with pytest.raises(MemoryError):
+            pl.host_alloc(1024, "float32")
