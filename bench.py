@@ -93,7 +93,20 @@ def cpu_baseline(iq_host, M, S, A, n, wall_budget):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
+    # one thread, one channel, same packets, a fraction of the budget
+    one = po.OracleComponent()
+    one.samplesPerBaud = S
+    one.constelationSize = M
+    one.numAvg = A
+    one.phaseAvg = n
+    t1 = time.perf_counter()
+    done1 = 0
+    while time.perf_counter() - t1 < wall_budget / 3:
+        one.service(iq_host[0], 0.01, sriChanged=(done1 == 0))
+        done1 += n_complex
+    dt1 = time.perf_counter() - t1
     return {
+        "single_thread_value": done1 / dt1 / 1e6,
         "value": total / dt / 1e6,
         "unit": "complex IQ Msamples/s",
         "cores": cores,
