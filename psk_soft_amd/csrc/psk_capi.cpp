@@ -26,7 +26,8 @@
 
 namespace psk {
 hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
-                       float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
+                       float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len,
+                       hipStream_t stream);
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 }  // namespace psk
@@ -383,6 +384,10 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // which kernels does this batch need?
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
     bool need_SH[17][5] = {};
+    // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
+    // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
+    // ring of r_len positions (even, >= numAvg + 128)
+    uint32_t max_n[17][5] = {}, max_A[17][5] = {};
     for (uint32_t i = 0; i < nch; i++) {
         const psk::ChanPlan &p = plans[i];
         if (p.mode == psk::PLAN_SKIP)
@@ -391,7 +396,10 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (p.mode == psk::PLAN_FAST) {
             if (p.n_out) {
                 any_emit = true;
-                need_SH[p.S][p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4] = true;
+                const int Hh = p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4;
+                need_SH[p.S][Hh] = true;
+                if (p.lf_n > max_n[p.S][Hh]) max_n[p.S][Hh] = p.lf_n;
+                if (p.A > max_A[p.S][Hh]) max_A[p.S][Hh] = p.A;
             } else {
                 any_quiet = true;
             }
@@ -413,15 +421,18 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                            stream));
     if (any_quiet)
         PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                 h->lim.fit_cap, stream));
+                                 h->lim.fit_cap, kFastFitMax + 128u, 0u, stream));
     // screened timing first; the exact-timing instantiation picks up the calls it refused, the
     // reference-order kernel (below) the calls both refused
     for (int exact = 0; exact <= 1; exact++)
         for (int S : kFastS)
             for (int H = exact ? 2 : 1; H <= 4; H++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
-                if (need_SH[S][H])
+                if (need_SH[S][H]) {
+                    const uint32_t y_len = max_n[S][H] + 128u <= 256u ? 256u : 512u;
+                    const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
                     PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
-                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, stream));
+                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, stream));
+                }
     if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
         PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                 h->lim.fit_cap, stream));

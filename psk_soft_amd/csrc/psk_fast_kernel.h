@@ -14,19 +14,39 @@ PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 
 // registers (numAvg <= 128 HV), EXACT = timing by the exact double pass (else the float
 // screening pass, see psk_fast_loop.h).  SV == 0 takes the channels of the batch that emit
 // nothing this call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
-// Register budget: the numAvg <= 128, samplesPerBaud <= 8 instantiations are held to 128 VGPRs
+// Register budget: the numAvg <= 128, samplesPerBaud <= 10 instantiations are held to 128 VGPRs
 // (4 waves per SIMD = 16 single-wave workgroups per CU, so a 4096-channel batch is resident at
-// once), samplesPerBaud = 10 to 168 (3 waves per SIMD); the others keep what they need.
+// once; samplesPerBaud = 10 pays for it with 11 spilled VGPRs and wins 20 % by the residency);
+// the others keep what they need.
 // Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
 // (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
 // runs on 1 and leaves 2.
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 10) ? 3 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
-                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
+                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
+                                                      uint32_t y_len, uint32_t r_len)
 {
-    __shared__ float yring[kYRing];
-    __shared__ __attribute__((aligned(16))) float ering[(SV != 0 && HV == 1) ? ering_floats(SV == 0 ? 2 : SV) : 4];
+    // LDS: [ring of unwrapped phases, a power of two >= phaseAvg + 128 floats][energy ring, numAvg <= 128
+    // only: SV rows].  Fixed sizes (512 floats, rows of 256) except samplesPerBaud = 10:
+    // dynamic LDS sized by the host for the launch (y_len floats, rows of r_len), see psk_fast_loop.h.
+    constexpr bool kDyn = ering_dynamic(SV);
+    float *yring;
+    uint32_t ymask;
+    ERingT<kDyn> er;
+    if constexpr (kDyn) {
+        extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+        yring = lds_dyn;
+        ymask = y_len - 1u;
+        er.mem = lds_dyn + y_len;
+        er.set_len((int)r_len);
+    } else {
+        __shared__ float yring_s[kYRing];
+        __shared__ __attribute__((aligned(16))) float ering_s[(SV != 0 && HV == 1) ? SV * kERing : 4];
+        yring = yring_s;
+        ymask = kYMask;
+        er.mem = ering_s;
+    }
     const int lane = threadIdx.x & 63;
     const ChanPlan &p = plans[blockIdx.x];
     if (p.mode != PLAN_FAST)
@@ -49,7 +69,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
 
     // ---- prologue: LinearFit history into the LDS ring; LinearFit::reset() sums if it ran ----
     const uint32_t len0 = p.lf_len0, n = p.lf_n;
-    for (uint32_t j = lane; j < len0; j += kWave) yring[j & kYMask] = yv[(p.lf_head + j) % fit_cap];
+    for (uint32_t j = lane; j < len0; j += kWave) yring[j & ymask] = yv[(p.lf_head + j) % fit_cap];
     wave_lds_fence();
     FastCarry cy;
     cy.ySum = st->lf_ySum;
@@ -71,19 +91,19 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
     cy.stat_extra = 0;
     cy.stat_exact_blocks = 0;
     if (p.lf_flags & LF_RECOMPUTE) {
-        fit_rebuild_sums([&](uint32_t j) { return yring[j & kYMask]; }, len0, p.lf_xdelta, cy.ySum, cy.xySum);
+        fit_rebuild_sums([&](uint32_t j) { return yring[j & ymask]; }, len0, p.lf_xdelta, cy.ySum, cy.xySum);
         fit_denominator(p.lf_xdelta, len0, cy.den, cy.xavg);
         if (len0 > 1) {
             (void)fit_value(cy.ySum, cy.xySum, p.lf_xdelta, len0, cy.den, cy.xavg, cy.m, cy.b);
         } else {
             cy.m = 0.0f;
-            cy.b = len0 ? yring[(len0 - 1) & kYMask] : 0.0f;
+            cy.b = len0 ? yring[(len0 - 1) & ymask] : 0.0f;
         }
     }
 
     // ---- the symbol loop ----
     if constexpr (SV != 0)
-        fast_main_loop<SV, HV, EXACT>(p, X, yring, ering, cy);
+        fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy);
 
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
     //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
@@ -123,17 +143,17 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
         long long numWraps = to_long_x86(__builtin_round((double)qv));
         float cst = (float)numWraps * wrapValue;
         for (uint32_t j = lane; j < len1; j += kWave) {  // LinearFit::subtractConst :126-133
-            float v = yring[(first + j) & kYMask];
-            yring[(first + j) & kYMask] = v - cst;
+            float v = yring[(first + j) & ymask];
+            yring[(first + j) & ymask] = v - cst;
         }
         wave_lds_fence();
-        fit_rebuild_sums([&](uint32_t j) { return yring[(first + j) & kYMask]; }, len1, p.lf_xdelta, cy.ySum, cy.xySum);
+        fit_rebuild_sums([&](uint32_t j) { return yring[(first + j) & ymask]; }, len1, p.lf_xdelta, cy.ySum, cy.xySum);
         fit_denominator(p.lf_xdelta, len1, cy.den, cy.xavg);
         if (len1 > 1) {
             pe = fit_value(cy.ySum, cy.xySum, p.lf_xdelta, len1, cy.den, cy.xavg, cy.m, cy.b);
         } else {
             cy.m = 0.0f;
-            cy.b = len1 ? yring[(first + len1 - 1) & kYMask] : 0.0f;
+            cy.b = len1 ? yring[(first + len1 - 1) & ymask] : 0.0f;
             pe = cy.b;
         }
         count1 = 1;  // informational only: the host mirrors LinearFit::count
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
     {
         const uint32_t dropped = grown - len1;
         const uint32_t head1 = (uint32_t)(((uint64_t)p.lf_head + dropped) % fit_cap);
-        for (uint32_t j = lane; j < len1; j += kWave) yv[(head1 + j) % fit_cap] = yring[(first + j) & kYMask];
+        for (uint32_t j = lane; j < len1; j += kWave) yv[(head1 + j) % fit_cap] = yring[(first + j) & ymask];
         const uint64_t drop = p.n_out * (uint64_t)p.S;  // samples popped by the emissions (:579-580)
         for (uint32_t j = lane; j < p.ring_len1; j += kWave) ring_dst[j] = x_at(X, drop + j);
         if (lane == 0) {
@@ -167,15 +187,16 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 8) ? 4 : (HV == 1 && SV <= 1
 
 #define PSK_FAST_ARGS                                                                                          \
     const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings, uint32_t ring_cap,    \
-        float *yvs, uint32_t fit_cap, hipStream_t stream
+        float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len, hipStream_t stream
 
 template <int SV, int HV, bool EXACT>
 hipError_t launch_fast_inst(PSK_FAST_ARGS)
 {
     if (!nch)
         return hipSuccess;
-    hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), 0, stream, plans, ch0, states, rings,
-                       ring_cap, yvs, fit_cap);
+    const size_t lds_bytes = ering_dynamic(SV) ? sizeof(float) * ((size_t)y_len + (size_t)SV * r_len) : 0;
+    hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, ch0, states,
+                       rings, ring_cap, yvs, fit_cap, y_len, r_len);
     return hipGetLastError();
 }
 

@@ -160,40 +160,66 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
     }
 }
 
-// numAvg <= 128 (H == 1): the energies of the last 256 symbol positions live in an LDS ring,
-// ering[k][position & 255], instead of registers.  A block writes its 128 positions (one 8-byte
-// store per phase: a lane's two positions are adjacent) and reads back the energies that sat
-// numAvg positions earlier -- part of them written a moment ago by other lanes, the rest by the
-// previous block.  No cross-lane permutes, no selects, and 2*S fewer live registers.
+// numAvg <= 128 (H == 1): the energies of the last R symbol positions live in an LDS ring,
+// ering[k][position mod R], instead of registers.  A block writes its 128 positions (one 8-byte
+// store per phase: a lane's two positions are adjacent and never straddle the wrap) and reads back
+// the energies that sat numAvg positions earlier -- part of them written a moment ago by other
+// lanes, the rest by the previous block.  No cross-lane permutes, no selects, and 2*S fewer live
+// registers.
+//   R = 256: every offset folds into the instructions (8 KiB at S = 8: 16 waves on a CU).
+//   samplesPerBaud = 10: R is chosen by the host per launch (dynamic LDS), even and at least
+//   numAvg + 128 for every channel of the launch: the shorter ring is what lets this instantiation
+//   keep 16 waves on a CU (8-PSK, S = 10: 2.92 -> 2.43 ms).  Its wrap is a compare and a select
+//   instead of a mask, which costs where residency is not the limit (S = 8: +1.5 %, S = 12: +7 %,
+//   S = 16: -1 %), hence only there.
 constexpr int kERing = 2 * kB;
+constexpr bool ering_dynamic(int S) { return S == 10; }
+template <bool DYN>
+struct ERingT;
+template <>
+struct ERingT<false> {
+    float *mem;
+    PSK_DEV void set_len(int) {}
+    PSK_DEV int length() const { return kERing; }
+    PSK_DEV int wrap(int i) const { return i & (kERing - 1); }
+    PSK_DEV float *row(int k) const { return mem + k * kERing; }
+};
+template <>
+struct ERingT<true> {
+    float *mem;
+    int len;  // R
+    PSK_DEV void set_len(int r) { len = r; }
+    PSK_DEV int length() const { return len; }
+    PSK_DEV int wrap(int i) const { return i < 0 ? i + len : (i >= len ? i - len : i); }  // i in (-R, 2R)
+    PSK_DEV float *row(int k) const { return mem + k * len; }
+};
 template <int S>
-PSK_DEV void ering_put(float *ering, int base, int lane, const float (&e)[kR][S])
+PSK_DEV void ering_put(const ERingT<ering_dynamic(S)> &er, int base, int lane, const float (&e)[kR][S])
 {
+    const int i = er.wrap(base + 2 * lane);
 #pragma unroll
-    for (int k = 0; k < S; k++)
-        *reinterpret_cast<float2 *>(ering + k * kERing + base + 2 * lane) = make_float2(e[0][k], e[1][k]);
+    for (int k = 0; k < S; k++) *reinterpret_cast<float2 *>(er.row(k) + i) = make_float2(e[0][k], e[1][k]);
 }
 template <int S>
-PSK_DEV void ering_get(const float *ering, int base, int lane, uint32_t D, float (&e)[kR][S])
+PSK_DEV void ering_get(const ERingT<ering_dynamic(S)> &er, int base, int lane, uint32_t D, float (&e)[kR][S])
 {
-    const int i0 = (base + 2 * lane - (int)D) & (kERing - 1);
+    const int i0 = er.wrap(base + 2 * lane - (int)D);
     if ((D & 1u) == 0) {  // the pair stays 8-byte aligned (and never straddles the wrap)
 #pragma unroll
         for (int k = 0; k < S; k++) {
-            const float2 t = *reinterpret_cast<const float2 *>(ering + k * kERing + i0);
+            const float2 t = *reinterpret_cast<const float2 *>(er.row(k) + i0);
             e[0][k] = t.x;
             e[1][k] = t.y;
         }
     } else {
-        const int i1 = (i0 + 1) & (kERing - 1);
+        const int i1 = er.wrap(i0 + 1);
 #pragma unroll
         for (int k = 0; k < S; k++) {
-            e[0][k] = ering[k * kERing + i0];
-            e[1][k] = ering[k * kERing + i1];
+            e[0][k] = er.row(k)[i0];
+            e[1][k] = er.row(k)[i1];
         }
     }
 }
-constexpr int ering_floats(int S) { return S * kERing; }
 
 // value of `field` in the block `back` blocks back in time (0 = cur, j >= 1 = hist[j-1]); back is
 // wave-uniform and at most H
@@ -221,7 +247,7 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
 template <bool WARM>
 PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk,
                       const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
-                      float *yring, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
+                      float *yring, uint32_t ymask, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
                       int lane_last, int r_last, float &den_last, float &xavg_last)
 {
     uint32_t before[kR];
@@ -272,14 +298,14 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             double yd = rawd[r] + (double)(long long)w[r] * two_pi;  // cpp/psk_soft.cpp:478
             y[r] = (float)yd;                                         // next(float yval), :481
             if (valid[r])
-                yring[before[r] & kYMask] = y[r];
+                yring[before[r] & ymask] = y[r];
             y_d[r] = (double)y[r];  // (positions past the end only feed sums past the end)
         }
         wave_lds_fence();
         float z[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++)
-            z[r] = steady[r] ? yring[(before[r] - n) & kYMask] : 0.0f;  // yvals.front(), :70
+            z[r] = steady[r] ? yring[(before[r] - n) & ymask] : 0.0f;  // yvals.front(), :70
         wave_lds_fence();
         const double dy0 = y_d[0] - (double)z[0], dy1 = y_d[1] - (double)z[1];
         double incl = wave_scan_f64(dy0 + dy1);
@@ -359,9 +385,10 @@ PSK_DEV float window_end_f32(const BlockKeep<S> (&hist)[H], uint32_t A, int lane
 
 // the same for numAvg <= 128 from the LDS ring: the window is the positions >= kB - A of the block
 // at `base`
-PSK_DEV float window_end_ring_f32(const float *ering, int base, uint32_t A, int lane, int k)
+template <bool DYN>
+PSK_DEV float window_end_ring_f32(const ERingT<DYN> &er, int base, uint32_t A, int lane, int k)
 {
-    const float2 t = *reinterpret_cast<const float2 *>(ering + k * kERing + base + 2 * lane);
+    const float2 t = *reinterpret_cast<const float2 *>(er.row(k) + er.wrap(base + 2 * lane));
     float acc = 0.0f;
     if (2 * lane >= kB - (int)A)
         acc += t.x;
@@ -415,21 +442,22 @@ PSK_DEV bool argtop_ambiguous(const ArgTop &t, float bound_abs)
 // (cpp/psk_soft.cpp:445-466).  Also returns the exact sums at the block's last position, rounded to
 // float, as fresh carries for the screening pass.  `base` = ring offset of the current block.
 template <int S>
-PSK_DEV void exact_block_from_ring(const float *ering, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
+PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
                                    const bool (&valid)[kR], float bound_abs)
 {
-    const int prev = base ^ kB;
-    const int i_old0 = (base + 2 * lane - (int)A) & (kERing - 1);
-    const int i_old1 = (i_old0 + 1) & (kERing - 1);
+    const int i_new = er.wrap(base + 2 * lane);
+    const int i_prev = er.wrap(base - kB + 2 * lane);
+    const int i_old0 = er.wrap(base + 2 * lane - (int)A);
+    const int i_old1 = er.wrap(i_old0 + 1);
     const bool in0 = 2 * lane >= kB - (int)A, in1 = 2 * lane + 1 >= kB - (int)A;
     ArgTop top[kR];
     argtop_first(top[0], 0.0);
     argtop_first(top[1], 0.0);
 #pragma unroll 1
     for (int k = 0; k < S; k++) {  // (a real loop: this path is rare, its registers and code size are not)
-        const float *row = ering + k * kERing;
-        const float2 en = *reinterpret_cast<const float2 *>(row + base + 2 * lane);
-        const float2 ep = *reinterpret_cast<const float2 *>(row + prev + 2 * lane);
+        const float *row = er.row(k);
+        const float2 en = *reinterpret_cast<const float2 *>(row + i_new);
+        const float2 ep = *reinterpret_cast<const float2 *>(row + i_prev);
         const float eo0 = row[i_old0], eo1 = row[i_old1];
         guard_track(cy, en.x);
         guard_track(cy, en.y);
@@ -458,7 +486,7 @@ PSK_DEV void exact_block_from_ring(const float *ering, int base, uint32_t A, int
 }
 
 template <int S, int H, bool EXACT>
-PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, float *ering, FastCarry &cy)
+PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uint32_t ymask, const ERingT<ering_dynamic(S)> &er, FastCarry &cy)
 {
 
     const int lane = threadIdx.x & 63;
@@ -533,8 +561,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
     const bool qpsk_sign_map = (p.lf_flags & PLAN_QPSK_SIGN_MAP) != 0;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
 
+    int ring_base = 0;  // (H == 1) ring offset of the current block
     if constexpr (H == 1)
-        ering_put<S>(ering, kB, lane, hist[0].e);  // block -1
+        ering_put<S>(er, er.length() - kB, lane, hist[0].e);  // block -1
 
     for (int c = 0; c < n_blocks; c++) {
         // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
@@ -570,10 +599,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         // i+A-1 did): all cross-lane fetches issued back to back
         float e_old[kR][S];
         if constexpr (H == 1) {
-            const int base = (c & 1) * kB;
-            ering_put<S>(ering, base, lane, cur.e);
+            ering_put<S>(er, ring_base, lane, cur.e);
             wave_lds_fence();
-            ering_get<S>(ering, base, lane, A, e_old);
+            ering_get<S>(er, ring_base, lane, A, e_old);
         } else {
 #pragma unroll
             for (int k = 0; k < S; k++) {
@@ -670,7 +698,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                     // settle this block exactly, here.  The float carries stay valid (still within
                     // their error bound); they are re-summed at the end of this block so that the
                     // bound, and with it the acceptance threshold, starts small again.
-                    exact_block_from_ring<S>(ering, (c & 1) * kB, A, lane, cy, bestK, valid,
+                    exact_block_from_ring<S>(er, ring_base, A, lane, cy, bestK, valid,
                                              2.0f * drift_bound(c * kB + kB, A) * wmax_prev);
                     since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
@@ -765,10 +793,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
         float den_last = den_s, xavg_last = xavg_s;
         int pass;
         if (__builtin_expect(q0 >= n, 1)) {
-            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
+            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, ymask, y, est, ySum_l, xySum_l,
                                     lane_last, r_last, den_last, xavg_last);
         } else {  // the fit window is still filling: the first phaseAvg symbols after a history clear
-            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, y, est, ySum_l, xySum_l,
+            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, ymask, y, est, ySum_l, xySum_l,
                                    lane_last, r_last, den_last, xavg_last);
         }
         if (pass > kMaxUnwrapPasses)
@@ -907,7 +935,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
 #pragma unroll
                 for (int k = 0; k < S; k++) {
                     if constexpr (H == 1)
-                        Wf[k] = window_end_ring_f32(ering, (c & 1) * kB, A, lane, k);
+                        Wf[k] = window_end_ring_f32(er, ring_base, A, lane, k);
                     else
                         Wf[k] = window_end_f32<S, H>(hist, A, lane, k);
                     wm = __builtin_fmaxf(wm, Wf[k]);
@@ -917,6 +945,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, flo
                 since_refresh = 0;
             }
         }
+        if constexpr (H == 1)
+            ring_base = er.wrap(ring_base + kB);
     }
 }
 

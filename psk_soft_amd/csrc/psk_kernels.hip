@@ -331,15 +331,15 @@ PSK_DECL_S(16)
 hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
 {
     if (S == 0)
-        return launch_fast_inst<0, 1, false>(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
+        return launch_fast_inst<0, 1, false>(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE(Sv, Hv)                                                                                              \
     if (S == Sv && H == Hv)                                                                                           \
-        return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream) \
-                     : launch_fast_S##Sv##_H##Hv##_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
+        return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream) \
+                     : launch_fast_S##Sv##_H##Hv##_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE1(Sv)                                                                                                 \
     if (S == Sv && H == 1)                                                                                            \
         return exact ? hipSuccess                                                                                     \
-                     : launch_fast_S##Sv##_H1_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, stream);
+                     : launch_fast_S##Sv##_H1_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE_S(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S(2)
     PSK_CASE_S(3)

@@ -215,6 +215,59 @@ def test_tie_heavy_signal_takes_the_exact_timing_path(oracle_mod):
     h2.close()
 
 
+def test_host_sized_energy_ring(oracle_mod):
+    """samplesPerBaud = 10 keeps its window energies in an LDS ring whose length the host picks per
+    launch from the largest numAvg (and the phase ring from the largest phaseAvg) among the launch's
+    channels: batches whose maxima differ, windows at both ends of the range, rectangular pulses
+    (near-ties settled from the ring in the kernel) and ragged packets so that ring offsets start
+    anywhere."""
+    import random as _random
+
+    from psk_soft_amd.stimulus import gen_psk, synth_channel
+
+    rng = random.Random(77)
+    for A_set, n_set in (((1, 2, 3, 28), (1, 10, 50)), ((76, 100, 5), (50, 128, 129)), ((127, 128, 64, 2), (384, 200, 1))):
+        props, iqs, cuts = [], [], []
+        for c in range(24):
+            M = (2, 4, 8)[c % 3]
+            p = dict(samplesPerBaud=10, constelationSize=M, numAvg=A_set[c % len(A_set)], phaseAvg=n_set[(c // 2) % len(n_set)],
+                     differentialDecoding=int(c % 5 == 0))
+            props.append(p)
+            if c % 4 == 3:
+                iq, _ = gen_psk(900 + 11 * c, samp_per_baud=10, num_syms=M, differential=False, rng=_random.Random(c))
+                iq = np.asarray(iq, np.float32)
+            else:
+                iq = synth_channel(7000 + c, M, 10, 9000 + 110 * c, sigma=(0.01, 0.1)[c % 2])
+            iqs.append(iq)
+            N = iq.size // 2
+            cuts.append([0] + sorted(rng.sample(range(1, N), 3)) + [N])
+        h = _handle(len(props))
+        h.configure(0, props)
+        got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in props]
+        n_exact = 0
+        for k in range(4):
+            pk = [dict(data=iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], xdelta=0.01, sriChanged=(k == 0)) for c in range(len(props))]
+            res = h.process_host(0, pk)
+            st = h.stats()
+            assert st["channels_sequential"] == 0, st
+            n_exact += st["timing_exact_blocks"]
+            for c in range(len(props)):
+                for key in got[c]:
+                    got[c][key].append(res[c][key])
+        assert n_exact > 0
+        for c in range(len(props)):
+            o = oracle_mod.OracleComponent()
+            for kk, v in props[c].items():
+                setattr(o, kk, v)
+            ref = dict(soft=[], bits=[], phase=[], index=[])
+            for k in range(4):
+                r = o.service(iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], 0.01, sriChanged=(k == 0))
+                ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+            assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, {k: np.concatenate(v) for k, v in ref.items()},
+                          "A=%s n=%s ch%d %s" % (A_set, n_set, c, props[c]))
+        h.close()
+
+
 def test_random_configuration_sweep(oracle_mod):
     """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
     and ragged packetisation, three calls each, every stream against the oracle: a broad net for
