@@ -133,6 +133,20 @@ private:
     bool stop_ = false;
 };
 
+// What the control-plane pass over a batch found out: the first refusal, if any, and which kernels
+// the accepted plans need.
+struct PlanSummary {
+    psk_soft_status st = PSK_SOFT_OK;
+    uint32_t bad = 0;  // first refused channel (index into the batch)
+    int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
+    bool any = false, any_emit = false, any_seq = false, any_quiet = false;
+    bool need_SH[17][5] = {};
+    // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
+    // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
+    // ring of r_len positions (even, >= numAvg + 128)
+    uint32_t max_n[17][5] = {}, max_A[17][5] = {};
+};
+
 // One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
 // packets and the packed four output streams, its own stream (so that the upload of one chunk, the
 // kernels of another and the download of a third overlap), and an event for "outputs are in host
@@ -168,6 +182,8 @@ struct psk_soft_handle {
     psk::Limits lim{};
     psk_soft_limits_t user{};
     std::vector<psk::ChanCtl> ctl;
+    std::vector<psk::ChanCtl> ctl_next;     // scratch of one call: planned on copies, committed on success
+    std::vector<psk::ChanPlan> plans_dry;   // plans of a control-plane-only handle (no pinned slots)
     std::vector<uint32_t> last_mode;  // PlanMode of the last call, per channel (statistics)
     // device memory
     psk::ChanState *d_state = nullptr;
@@ -215,6 +231,7 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->lim.fast_fit_max = kFastFitMax;
     h->lim.force_seq = false;
     h->ctl.resize(n_channels);
+    h->ctl_next.resize(n_channels);
     h->last_mode.assign(n_channels, psk::PLAN_SKIP);
     h->device = device;
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
@@ -352,71 +369,96 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
 {
     if (!h || !pkts || !outs || !nch || (uint64_t)ch0 + nch > h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process: bad arguments");
-    // plan on copies; commit only if every channel of the batch is accepted
-    std::vector<psk::ChanCtl> next(h->ctl.begin() + ch0, h->ctl.begin() + ch0 + nch);
-    std::vector<psk::ChanPlan> plans(nch);
-    for (uint32_t i = 0; i < nch; i++) {
-        if (next[i].props.samplesPerBaud > kSeqMaxS)
+    // The plans are written straight into the pinned upload slot of this call: wait until the launch
+    // that last used the slot has consumed it.  (A refused call does not advance the slot.)
+    const int slot = h->slot;
+    psk::ChanPlan *plans;
+    if (h->dry) {
+        if (h->plans_dry.size() < nch)
+            h->plans_dry.resize(nch);
+        plans = h->plans_dry.data();
+    } else {
+        PSK_HIP(hipSetDevice(h->device));
+        if (h->ev_used[slot])
+            PSK_HIP(hipEventSynchronize(h->ev[slot]));
+        plans = h->h_plans[slot];
+    }
+    // plan on copies (ctl_next); commit only if every channel of the batch is accepted
+    const bool dry = h->dry;
+    const uint32_t extra_flags = h->opt_qpsk_sign_map ? (uint32_t)psk::PLAN_QPSK_SIGN_MAP : 0u;
+    psk::ChanCtl *const next = h->ctl_next.data() + ch0;
+    const psk::ChanCtl *const cur = h->ctl.data() + ch0;
+    const psk::Limits lim = h->lim;
+    auto plan_range = [&](uint32_t lo, uint32_t hi, PlanSummary &r) {
+        for (uint32_t i = lo; i < hi; i++) {
+            next[i] = cur[i];
+            if (next[i].props.samplesPerBaud > kSeqMaxS) {
+                r.st = PSK_SOFT_ERR_LIMIT, r.bad = i, r.why = 1;
+                return;
+            }
+            psk::ChanPlan &p = plans[i];
+            psk_soft_status st = psk::plan_call(next[i], lim, pkts[i], outs[i], p);
+            if (st != PSK_SOFT_OK) {
+                r.st = st, r.bad = i, r.why = 0;
+                return;
+            }
+            if (p.mode == psk::PLAN_SKIP)
+                continue;
+            if (!dry && ((p.n_in && !p.in) || ((uintptr_t)p.in & 7u) || ((uintptr_t)p.soft & 7u) ||
+                         ((uintptr_t)p.bits & 3u) || ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 3u))) {
+                r.st = PSK_SOFT_ERR_INVALID_ARG, r.bad = i, r.why = 2;
+                return;
+            }
+            p.lf_flags |= extra_flags;
+            r.any = true;
+            if (p.mode == psk::PLAN_FAST) {
+                if (p.n_out) {
+                    r.any_emit = true;
+                    const int Hh = p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4;
+                    r.need_SH[p.S][Hh] = true;
+                    if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
+                    if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
+                } else {
+                    r.any_quiet = true;
+                }
+            } else {
+                r.any_seq = true;
+            }
+        }
+    };
+    // One thread: the pass is ~15 ns and ~0.5 KB of cache traffic per channel (60 us for 4096
+    // channels).  Splitting it over a thread pool was measured and dropped: the workers' share is
+    // done in 10-20 us, after which they sleep until the next call, and waking them costs more than
+    // the whole pass (spinning instead would burn cores between packets).
+    PlanSummary res;
+    plan_range(0, nch, res);
+    if (res.st != PSK_SOFT_OK) {
+        if (res.why == 1)
             return fail(PSK_SOFT_ERR_LIMIT, "samplesPerBaud > 1024");
-        psk_soft_status st = psk::plan_call(next[i], h->lim, pkts[i], outs[i], plans[i]);
-        if (st != PSK_SOFT_OK) {
-            char buf[160];
-            std::snprintf(buf, sizeof buf, "psk_soft_process: channel %u refused (status %d)", ch0 + i, (int)st);
-            return fail(st, buf);
-        }
-        if (!h->dry && plans[i].mode != psk::PLAN_SKIP) {
-            const psk::ChanPlan &p = plans[i];
-            if ((p.n_in && !p.in) || ((uintptr_t)p.in & 7u) || ((uintptr_t)p.soft & 7u) || ((uintptr_t)p.bits & 3u) ||
-                ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 3u))
-                return fail(PSK_SOFT_ERR_INVALID_ARG,
-                            "psk_soft_process: packet data must be 8-byte aligned, soft 8, bits 4, phase 4, sampleIndex 4");
-        }
+        if (res.why == 2)
+            return fail(PSK_SOFT_ERR_INVALID_ARG,
+                        "psk_soft_process: packet data must be 8-byte aligned, soft 8, bits 4, phase 4, sampleIndex 4");
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "psk_soft_process: channel %u refused (status %d)", ch0 + res.bad, (int)res.st);
+        return fail(res.st, buf);
     }
-    for (uint32_t i = 0; i < nch; i++) {
-        h->ctl[ch0 + i] = next[i];
-        h->last_mode[ch0 + i] = plans[i].mode;
-        if (h->opt_qpsk_sign_map)
-            plans[i].lf_flags |= psk::PLAN_QPSK_SIGN_MAP;
-    }
+    // commit
+    if (ch0 == 0 && nch == h->nch)
+        h->ctl.swap(h->ctl_next);
+    else
+        std::memcpy(static_cast<void *>(h->ctl.data() + ch0), next, sizeof(psk::ChanCtl) * nch);
+    for (uint32_t i = 0; i < nch; i++) h->last_mode[ch0 + i] = plans[i].mode;
     if (h->dry)
         return PSK_SOFT_OK;
-
-    // which kernels does this batch need?
-    bool any = false, any_emit = false, any_seq = false, any_quiet = false;
-    bool need_SH[17][5] = {};
-    // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
-    // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
-    // ring of r_len positions (even, >= numAvg + 128)
-    uint32_t max_n[17][5] = {}, max_A[17][5] = {};
-    for (uint32_t i = 0; i < nch; i++) {
-        const psk::ChanPlan &p = plans[i];
-        if (p.mode == psk::PLAN_SKIP)
-            continue;
-        any = true;
-        if (p.mode == psk::PLAN_FAST) {
-            if (p.n_out) {
-                any_emit = true;
-                const int Hh = p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4;
-                need_SH[p.S][Hh] = true;
-                if (p.lf_n > max_n[p.S][Hh]) max_n[p.S][Hh] = p.lf_n;
-                if (p.A > max_A[p.S][Hh]) max_A[p.S][Hh] = p.A;
-            } else {
-                any_quiet = true;
-            }
-        } else {
-            any_seq = true;
-        }
-    }
+    const bool any = res.any, any_emit = res.any_emit, any_seq = res.any_seq, any_quiet = res.any_quiet;
+    const auto &need_SH = res.need_SH;
+    const auto &max_n = res.max_n;
+    const auto &max_A = res.max_A;
     if (!any)
         return PSK_SOFT_OK;
 
-    PSK_HIP(hipSetDevice(h->device));
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : h->stream;
-    const int slot = h->slot;
     h->slot = (h->slot + 1) % kPlanSlots;
-    if (h->ev_used[slot])
-        PSK_HIP(hipEventSynchronize(h->ev[slot]));
-    std::memcpy(h->h_plans[slot], plans.data(), sizeof(psk::ChanPlan) * nch);
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
                            stream));
     if (any_quiet)

@@ -234,6 +234,65 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
     return v;
 }
 
+// Between two exact passes of fit_block: settle the knock-on effects of the corrections a pass has
+// just found, cheaply, so that the next exact pass (normally) only has to confirm.
+// A count that changes by d_j at position j moves y_j by 2 pi d_j, and with it every later
+// estimate that still has j in its window of n values: the endpoint of a least-squares line
+// through n equidistant points weighs the point of age t with (4n-2)/(n(n+1)) - 6t/(n(n+1)), so
+//     est'_s - est_s = 2 pi (alpha D0_s - beta D1_s),  D0_s = sum_{j in (s-n, s]} d_j,  D1_s = sum (s-j) d_j.
+// Both windowed sums come from ONE integer prefix scan of d_j (65536 j + 1) and two ds_bpermute
+// (low half: sum d_j, high half: sum j d_j).  Every position then re-derives its count from the
+// shifted estimate of its predecessor, as a DIFFERENCE to what the unshifted estimate gives in
+// the same float formula (so that where nothing moved, the exact count w2 stands), and the step
+// repeats until nothing changes.  This is a guess: everything is verified by the exact pass that
+// follows, an overflow of the packed sums or a float near-tie only costs another pass.
+constexpr int kRefineMax = 12;
+PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&est)[kR], const double (&rawd)[kR],
+                           const bool (&valid)[kR], const int (&w_base)[kR], int (&w2)[kR])
+{
+    const float inv2pi = 0.15915494f;
+    const float nn = (float)n * (float)(n + 1u);
+    const float alpha = 6.2831853f * (float)(4u * n - 2u) / nn, beta = 6.2831853f * 6.0f / nn;
+    const int s0 = 2 * lane, s1 = s0 + 1;
+    const float raw0 = (float)rawd[0], raw1 = (float)rawd[1];
+    const float qb0 = __builtin_rintf((est_prev0 - raw0) * inv2pi), qb1 = __builtin_rintf((est[0] - raw1) * inv2pi);
+    int d0 = valid[0] ? w2[0] - w_base[0] : 0, d1 = valid[1] ? w2[1] - w_base[1] : 0;
+    // where position s - n lives (n < 128; otherwise the window reaches back past the block start)
+    const bool windowed = n < (uint32_t)kB;
+    const int la = lane - (int)((n + 1u) >> 1);  // n even: both positions from lane - n/2
+    const int lb = (n & 1u) ? la + 1 : la;       // n odd: s0 - n = slot 1 of la, s1 - n = slot 0 of la + 1
+#pragma unroll 1
+    for (int it = 0; it < kRefineMax; it++) {
+        const int v0 = d0 * (65536 * s0 + 1), v1 = d1 * (65536 * s1 + 1);
+        const int incl = wave_scan_i32(v0 + v1);
+        const int x0 = wave_up1(incl, 0) + v0, x1 = x0 + v1;
+        int z0 = 0, z1 = 0;
+        if (windowed) {
+            const int a = __builtin_amdgcn_ds_bpermute(la << 2, (n & 1u) ? x1 : x0);
+            const int b = __builtin_amdgcn_ds_bpermute(lb << 2, (n & 1u) ? x0 : x1);
+            z0 = la >= 0 ? a : 0;
+            z1 = lb >= 0 ? b : 0;
+        }
+        const int y0 = x0 - z0, y1 = x1 - z1;
+        const int D0a = (y0 << 16) >> 16, D0b = (y1 << 16) >> 16;  // sum of d_j over the window
+        const int J0 = (y0 - D0a) >> 16, J1 = (y1 - D0b) >> 16;    // sum of j d_j over the window
+        const float de0 = alpha * (float)D0a - beta * (float)(s0 * D0a - J0);
+        const float de1 = alpha * (float)D0b - beta * (float)(s1 * D0b - J1);
+        const float dp0 = wave_up1(de1, 0.0f);  // shift of the estimate fed back at s0
+        const float q0 = __builtin_rintf((est_prev0 + dp0 - raw0) * inv2pi);
+        const float q1 = __builtin_rintf((est[0] + de0 - raw1) * inv2pi);
+        const int nd0 = valid[0] ? w2[0] + (int)(q0 - qb0) - w_base[0] : 0;
+        const int nd1 = valid[1] ? w2[1] + (int)(q1 - qb1) - w_base[1] : 0;
+        const bool changed = nd0 != d0 || nd1 != d1;
+        d0 = nd0;
+        d1 = nd1;
+        if (!__any(changed))
+            break;
+    }
+    w2[0] = w_base[0] + d0;
+    w2[1] = w_base[1] + d1;
+}
+
 // One block (128 symbols) of the feedback unwrap + LinearFit::next recurrence
 // (reference cpp/psk_soft.cpp:477-482, 48-87, 135-174).  The recurrence
 //     est[i-1] -> numWraps[i] -> y[i] -> (ySum, xySum) -> est[i]
@@ -351,8 +410,13 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
         if (!__any(bad))
             break;
-        w[0] = w2_0;
-        w[1] = w2_1;
+        int w2[kR] = {w2_0, w2_1};
+#ifndef PSK_NO_REFINE
+        if (!WARM)
+            refine_unwrap(lane, n, est_prev0, est, rawd, valid, w, w2);
+#endif
+        w[0] = w2[0];
+        w[1] = w2[1];
         if (++pass > kMaxUnwrapPasses)
             break;
     }

@@ -81,6 +81,49 @@ def test_random_call_sequences(oracle_mod, seed):
         assert pk["fit_len"] == o.fit_history().size, ctx
 
 
+def test_large_batch_equals_channel_by_channel():
+    """A whole-handle batch is planned on a scratch copy of the channel states that is swapped in on
+    success (a partial range is copied back); the results, the committed state, the refusal reported
+    and the roll-back of a refused call must be those of a one-channel-at-a-time pass."""
+    rng = random.Random(99)
+    n_ch = 3000
+    big = pl.Handle(n_ch, device=pl.DEVICE_NONE, max_window_samples=1 << 14, max_phase_avg=512)
+    one = pl.Handle(n_ch, device=pl.DEVICE_NONE, max_window_samples=1 << 14, max_phase_avg=512)
+    props = [dict(samplesPerBaud=rng.choice([1, 2, 5, 8, 10, 16]), constelationSize=rng.choice([2, 4, 8, 3]),
+                  numAvg=rng.choice([0, 1, 25, 100, 400]), phaseAvg=rng.choice([1, 50, 200, 500]),
+                  differentialDecoding=rng.choice([0, 1])) for _ in range(n_ch)]
+    big.configure(0, props)
+    one.configure(0, props)
+    for call in range(6):
+        pk = [None if rng.random() < 0.05 else
+              dict(n_floats=2 * rng.choice([0, 3, 64, 777, 4096]) + (rng.random() < 0.05), xdelta=rng.choice([0.01, 0.5]),
+                   sriChanged=(call == 0), inputQueueFlushed=(rng.random() < 0.02), mode=(0 if rng.random() < 0.02 else 1))
+              for _ in range(n_ch)]
+        if call == 3:  # a refused call: one channel in the middle asks for an unsupported property
+            bad = 1777
+            big.configure(bad, [dict(phaseAvg=0)])
+            before = [big.peek(c) for c in (0, bad - 1, bad, bad + 1, n_ch - 1)]
+            with pytest.raises(pl.PskSoftError) as ei:
+                big.plan_only(0, pk)
+            assert "channel %d " % bad in str(ei.value)
+            assert [big.peek(c) for c in (0, bad - 1, bad, bad + 1, n_ch - 1)] == before
+            big.configure(bad, [dict(phaseAvg=props[bad]["phaseAvg"])])
+            one.configure(bad, [dict(phaseAvg=0)])  # same listener traffic on the other side
+            one.configure(bad, [dict(phaseAvg=props[bad]["phaseAvg"])])
+        got = big.plan_only(0, pk)
+        ref = [one.plan_only(c, [pk[c]])[0] for c in range(n_ch)]
+        assert got == ref, call
+        assert [big.peek(c) for c in range(0, n_ch, 7)] == [one.peek(c) for c in range(0, n_ch, 7)]
+    # a partial range of a large handle (no swap of the state arrays)
+    pk = [dict(n_floats=2 * 1000, xdelta=0.01) for _ in range(1500)]
+    got = big.plan_only(700, pk)
+    ref = [one.plan_only(700 + c, [pk[c]])[0] for c in range(1500)]
+    assert got == ref
+    assert [big.peek(c) for c in range(0, n_ch, 11)] == [one.peek(c) for c in range(0, n_ch, 11)]
+    big.close()
+    one.close()
+
+
 def test_no_packet_is_noop(oracle_mod):
     h, _ = _mk(oracle_mod)
     r = h.plan_only(0, [None])[0]
