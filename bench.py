@@ -222,6 +222,9 @@ def main():
     # HIP events on the stream the kernels run on
     dev_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    # the box's empirical read ceiling over the same input buffer: 16-byte
+    # loads and nothing else, so that "% of peak" and "% of achievable" can both be stated
+    probe_ms = h.probe_read_ms(iq.data_ptr(), iq.numel() * 4, reps=5)
     st = h.stats()
     n_out = int(out[0].n_symbols)
 
@@ -275,6 +278,8 @@ def main():
             "algorithmic_write_bytes_per_launch": alg_write_bytes,
             "launch_ms_avg": dev_ms_avg,
             "launch_ms_min": dev_ms[0],
+            "empirical_read_ceiling": alg_read_bytes / (probe_ms * 1e-3) / 1e9,
+            "frac_of_empirical_read_ceiling": probe_ms / dev_ms_avg,
         },
         "kernel_stats": st,
     }

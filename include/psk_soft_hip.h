@@ -179,6 +179,13 @@ psk_soft_status psk_soft_set_force_sequential(psk_soft_handle_t *h, int on);
 void *psk_soft_host_alloc(size_t bytes);
 void psk_soft_host_free(void *p);
 
+/* Measurement support ("the empirical ceiling on the box -- a pure float4
+ * read-reduce kernel over the same buffer"): reads `bytes` of device memory at `dev_ptr` (16-byte
+ * aligned) `reps` times with 16-byte loads, nothing else, and returns the mean duration of one pass in
+ * milliseconds, timed with HIP events on the handle's stream.  No counterpart in the reference. */
+psk_soft_status psk_soft_probe_read_ms(psk_soft_handle_t *h, const void *dev_ptr, uint64_t bytes, int reps,
+                                       double *ms_per_pass);
+
 /* checkpoint / test support: opaque state blob of one channel */
 uint64_t psk_soft_state_bytes(const psk_soft_handle_t *h);
 psk_soft_status psk_soft_export_state(psk_soft_handle_t *h, uint32_t ch, void *dst, uint64_t cap);

@@ -30,6 +30,7 @@ hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, uint32_t 
                        hipStream_t stream);
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
+hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipStream_t stream);
 }  // namespace psk
 
 namespace {
@@ -812,6 +813,30 @@ psk_soft_status psk_soft_import_state(psk_soft_handle_t *h, uint32_t ch, const v
     PSK_HIP(hipMemcpy(ring, p, sizeof(float2) * h->lim.ring_cap, hipMemcpyHostToDevice));
     p += sizeof(float2) * h->lim.ring_cap;
     PSK_HIP(hipMemcpy(h->d_yv + (size_t)ch * h->lim.fit_cap, p, sizeof(float) * h->lim.fit_cap, hipMemcpyHostToDevice));
+    return PSK_SOFT_OK;
+}
+
+psk_soft_status psk_soft_probe_read_ms(psk_soft_handle_t *h, const void *dev_ptr, uint64_t bytes, int reps,
+                                       double *ms_per_pass)
+{
+    if (!h || h->dry || !dev_ptr || bytes < 16 || ((uintptr_t)dev_ptr & 15u) || reps < 1 || !ms_per_pass)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_probe_read_ms: needs a device handle, a 16-byte aligned device "
+                                              "pointer, at least 16 bytes and one repetition");
+    PSK_HIP(hipSetDevice(h->device));
+    hipEvent_t e0, e1;
+    PSK_HIP(hipEventCreate(&e0));
+    PSK_HIP(hipEventCreate(&e1));
+    float *sink = reinterpret_cast<float *>(h->d_state);  // (never written: see the kernel)
+    PSK_HIP(psk::launch_read_probe(dev_ptr, bytes, sink, h->stream));  // untimed first pass
+    PSK_HIP(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; r++) PSK_HIP(psk::launch_read_probe(dev_ptr, bytes, sink, h->stream));
+    PSK_HIP(hipEventRecord(e1, h->stream));
+    PSK_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PSK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_pass = (double)ms / reps;
     return PSK_SOFT_OK;
 }
 

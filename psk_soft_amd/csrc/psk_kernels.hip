@@ -363,4 +363,34 @@ hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanSta
                        fit_cap);
     return hipGetLastError();
 }
+// Measurement support: the empirical read ceiling -- 16-byte loads over a
+// buffer, summed, nothing written (the sum only reaches memory if it is NaN-free and equals a value
+// it cannot have).  4 independent loads per thread in flight, grid-stride, 2048 workgroups of 256.
+__global__ __launch_bounds__(256) void psk_read_probe_kernel(const float4 *__restrict__ src, uint64_t n_vec,
+                                                             float *__restrict__ sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc.x += a.x + b.x + c.x + d.x;
+        acc.y += a.y + b.y + c.y + d.y;
+        acc.z += a.z + b.z + c.z + d.z;
+        acc.w += a.w + b.w + c.w + d.w;
+    }
+    for (; i < n_vec; i += stride) {
+        const float4 a = src[i];
+        acc.x += a.x, acc.y += a.y, acc.z += a.z, acc.w += a.w;
+    }
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 1.2345678e-30f)
+        *sink = t;
+}
+
+hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipStream_t stream)
+{
+    hipLaunchKernelGGL(psk_read_probe_kernel, dim3(2048), dim3(256), 0, stream, (const float4 *)src, bytes / 16u, sink);
+    return hipGetLastError();
+}
 }  // namespace psk

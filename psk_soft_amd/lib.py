@@ -93,6 +93,7 @@ class Stats(ctypes.Structure):
 
 # every symbol include/psk_soft_hip.h declares
 EXPORTS = (
+    "psk_soft_probe_read_ms",
     "psk_soft_set_option",
     "psk_soft_host_alloc",
     "psk_soft_host_free",
@@ -160,6 +161,7 @@ def load():
     L.psk_soft_host_alloc.argtypes = [ctypes.c_size_t]
     L.psk_soft_host_alloc.restype = vp
     L.psk_soft_host_free.argtypes = [vp]
+    L.psk_soft_probe_read_ms.argtypes = [vp, vp, u64, i32, ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 
@@ -356,6 +358,12 @@ class Handle:
 
     def synchronize(self):
         _check(self._L.psk_soft_synchronize(self._h))
+
+    def probe_read_ms(self, dev_ptr, nbytes, reps=5):
+        """Mean duration (ms) of one pure 16-byte-load pass over a device buffer (empirical read ceiling)."""
+        ms = ctypes.c_double()
+        _check(self._L.psk_soft_probe_read_ms(self._h, ctypes.c_void_p(dev_ptr), int(nbytes), int(reps), ctypes.byref(ms)))
+        return ms.value
 
     def stats(self):
         s = Stats()
