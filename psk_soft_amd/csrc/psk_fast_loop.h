@@ -503,26 +503,55 @@ PSK_DEV bool argtop_ambiguous(const ArgTop &t, float bound_abs)
 // screened kernel when its margin test fails somewhere in the block: window sums of float-valued
 // energies accumulated in double (exact under the exponent-spread guard, which is fed here and
 // evaluated at the end of the kernel), the reference's first-maximum rule
-// (cpp/psk_soft.cpp:445-466).  Also returns the exact sums at the block's last position, rounded to
-// float, as fresh carries for the screening pass.  `base` = ring offset of the current block.
+// (cpp/psk_soft.cpp:445-466).  `base` = ring offset of the current block.
+// Only the positions that failed the test are re-decided, and only the phases that contend there
+// are summed exactly: the best and the runner-up of the screening at those positions, plus every
+// other phase whose float sum -- recomputed here from the ring with the screening's own scan, hence
+// within its error bound -- is not below best - thr at every failing position (thr covers twice the
+// bound, see the screening pass).  On a shaped pulse two phases contend, so a redo costs two double scans
+// and S - 2 float ones instead of S double ones.  (A NaN compares false: such a phase stays in.)
 template <int S>
 PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
-                                   const bool (&valid)[kR], float bound_abs)
+                                   float bound_abs, const bool (&fail)[kR], const float (&best_f)[kR],
+                                   const int (&second_k)[kR], float thr)
 {
     const int i_new = er.wrap(base + 2 * lane);
     const int i_prev = er.wrap(base - kB + 2 * lane);
     const int i_old0 = er.wrap(base + 2 * lane - (int)A);
     const int i_old1 = er.wrap(i_old0 + 1);
     const bool in0 = 2 * lane >= kB - (int)A, in1 = 2 * lane + 1 >= kB - (int)A;
+    // contenders at the failing positions, wave-wide
+    unsigned mine = 0;
+#pragma unroll
+    for (int r = 0; r < kR; r++)
+        if (fail[r])
+            mine |= (1u << bestK[r]) | (1u << second_k[r]);
+    unsigned cand = 0;
+#pragma unroll
+    for (int k = 0; k < S; k++)
+        if (__any((mine >> k) & 1u))
+            cand |= 1u << k;
     ArgTop top[kR];
     argtop_first(top[0], 0.0);
     argtop_first(top[1], 0.0);
+    bool first = true;
 #pragma unroll 1
     for (int k = 0; k < S; k++) {  // (a real loop: this path is rare, its registers and code size are not)
         const float *row = er.row(k);
         const float2 en = *reinterpret_cast<const float2 *>(row + i_new);
-        const float2 ep = *reinterpret_cast<const float2 *>(row + i_prev);
         const float eo0 = row[i_old0], eo1 = row[i_old1];
+        if (!((cand >> k) & 1u)) {  // (wave-uniform) not a contender by the screening: make sure in float
+            const float d0 = en.x - eo0, d1 = en.y - eo1;
+            const float incl = wave_scan_f32(d0 + d1);
+            // the float sum at the block's last position, re-summed from the ring (within 16 ulp)
+            const float w_end = read_lane(wave_scan_f32((in0 ? en.x : 0.0f) + (in1 ? en.y : 0.0f)), 63);
+            const float W1 = (w_end - read_lane(incl, 63)) + incl;
+            const float W0 = W1 - d1;
+            const bool below = (!fail[0] || W0 < best_f[0] - thr) && (!fail[1] || W1 < best_f[1] - thr);
+            if (__all(below))
+                continue;
+        }
+        const float2 ep = *reinterpret_cast<const float2 *>(row + i_prev);
         guard_track(cy, en.x);
         guard_track(cy, en.y);
         guard_track(cy, ep.x);
@@ -534,9 +563,11 @@ PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base,
         const double d0 = (double)en.x - (double)eo0, d1 = (double)en.y - (double)eo1;
         const double W1 = Wc + wave_scan_f64(d0 + d1);
         const double W0 = W1 - d1;
-        if (k == 0) {
+        if (first) {
             argtop_first(top[0], W0);
             argtop_first(top[1], W1);
+            top[0].k = top[1].k = k;
+            first = false;
         } else {
             argtop_next(top[0], W0, k);
             argtop_next(top[1], W1, k);
@@ -544,8 +575,10 @@ PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base,
     }
 #pragma unroll
     for (int r = 0; r < kR; r++) {
-        bestK[r] = top[r].k;
-        cy.ambiguous = cy.ambiguous || (valid[r] && argtop_ambiguous(top[r], bound_abs));
+        if (fail[r]) {
+            bestK[r] = top[r].k;
+            cy.ambiguous = cy.ambiguous || argtop_ambiguous(top[r], bound_abs);
+        }
     }
 }
 
@@ -762,8 +795,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                     // settle this block exactly, here.  The float carries stay valid (still within
                     // their error bound); they are re-summed at the end of this block so that the
                     // bound, and with it the acceptance threshold, starts small again.
-                    exact_block_from_ring<S>(er, ring_base, A, lane, cy, bestK, valid,
-                                             2.0f * drift_bound(c * kB + kB, A) * wmax_prev);
+                    const bool fail[kR] = {!ok0, !ok1};
+                    const float best_f[kR] = {__int_as_float(m1[0]), __int_as_float(m1[1])};
+                    const int second_k[kR] = {IMASK - (m2[0] & IMASK), IMASK - (m2[1] & IMASK)};
+                    exact_block_from_ring<S>(er, ring_base, A, lane, cy, bestK,
+                                             2.0f * drift_bound(c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr);
                     since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
                 } else {
