@@ -29,9 +29,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MIC
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10,
-                    help="untimed steps; the first ~8 launches of a process run 2-8 %% slower (clock ramp), see DESIGN.md")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30,
+                    help="untimed steps; the first ~30 launches of a process (75 ms) run up to 12 %% slower, "
+                         "tools/launch_ramp.py and DESIGN.md section 3.1")
     ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
     ap.add_argument("--nsamp", type=int, default=1 << 18, help="complex samples per channel per step")
     ap.add_argument("--M", type=int, default=4)

@@ -1,0 +1,40 @@
+"""Per-launch duration of the headline configuration over a long run of back-to-back steps (diagnostic:
+how long the first-launches ramp of a fresh process lasts).  usage (GPU box): python tools/launch_ramp.py [steps]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from psk_soft_amd import lib as pl  # noqa: E402
+from psk_soft_amd.stimulus import synth_channels_torch  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+C, N, S, M = 4096, 1 << 18, 8, 4
+dev = torch.device("cuda", 0)
+iq = synth_channels_torch(C, M, S, N, dev, periodic=True)
+cap = (N // S + 2 + 63) // 64 * 64
+soft = torch.empty((C, 2 * cap), dtype=torch.float32, device=dev)
+phase = torch.empty((C, cap), dtype=torch.float32, device=dev)
+sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)
+bits = torch.empty((C, 2 * cap), dtype=torch.int16, device=dev)
+pk = (pl.Packet * C)()
+out = (pl.Output * C)()
+for c in range(C):
+    pk[c].data = iq[c].data_ptr(); pk[c].n_floats = 2 * N; pk[c].sri_xdelta = 0.01; pk[c].sri_mode = 1; pk[c].present = 1
+    out[c].soft = soft[c].data_ptr(); out[c].bits = bits[c].data_ptr(); out[c].phase = phase[c].data_ptr()
+    out[c].sampleIndex = sidx[c].data_ptr(); out[c].cap_symbols = cap
+h = pl.Handle(C, device=0)
+h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=50)
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+ev[0].record(stream)
+for k in range(steps):
+    h.process_device(0, pk, out, stream=stream.cuda_stream)
+    ev[k + 1].record(stream)
+torch.cuda.synchronize()
+ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]
+for a in range(0, steps, 10):
+    print("steps %3d-%3d: mean %.3f ms" % (a, a + 9, sum(ms[a:a + 10]) / len(ms[a:a + 10])))
