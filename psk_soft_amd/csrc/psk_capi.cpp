@@ -172,7 +172,7 @@ inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 384;  // LDS y ring of the wave-scan kernel: 512 - 128
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
-const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 10, 12, 16};
+const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
 }  // namespace
 

@@ -73,12 +73,12 @@ struct Limits {
     bool force_seq;
 };
 
-// instantiations of the wave-scan kernel: samplesPerBaud in {2,3,4,5,6,7,8,10,12,16}, numAvg <= 512
+// instantiations of the wave-scan kernel: samplesPerBaud 2 .. 16, numAvg <= 512
 // (window history of ceil(numAvg/128) <= 4 blocks in registers)
 constexpr uint32_t kFastMaxNumAvg = 512;
 inline bool fast_kernel_has_S(uint32_t S)
 {
-    return (S >= 2 && S <= 8) || S == 10 || S == 12 || S == 16;
+    return S >= 2 && S <= 16;
 }
 
 // LinearFit::reset(numPts, sampleRate, forceHistoryClear) on the control state,

@@ -167,13 +167,13 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
 // lanes, the rest by the previous block.  No cross-lane permutes, no selects, and 2*S fewer live
 // registers.
 //   R = 256: every offset folds into the instructions (8 KiB at S = 8: 16 waves on a CU).
-//   samplesPerBaud = 10: R is chosen by the host per launch (dynamic LDS), even and at least
+//   samplesPerBaud = 9, 10: R is chosen by the host per launch (dynamic LDS), even and at least
 //   numAvg + 128 for every channel of the launch: the shorter ring is what lets this instantiation
 //   keep 16 waves on a CU (8-PSK, S = 10: 2.92 -> 2.43 ms).  Its wrap is a compare and a select
 //   instead of a mask, which costs where residency is not the limit (S = 8: +1.5 %, S = 12: +7 %,
 //   S = 16: -1 %), hence only there.
 constexpr int kERing = 2 * kB;
-constexpr bool ering_dynamic(int S) { return S == 10; }
+constexpr bool ering_dynamic(int S) { return S == 9 || S == 10; }
 template <bool DYN>
 struct ERingT;
 template <>

@@ -322,8 +322,13 @@ PSK_DECL_S(5)
 PSK_DECL_S(6)
 PSK_DECL_S(7)
 PSK_DECL_S(8)
+PSK_DECL_S(9)
 PSK_DECL_S(10)
+PSK_DECL_S(11)
 PSK_DECL_S(12)
+PSK_DECL_S(13)
+PSK_DECL_S(14)
+PSK_DECL_S(15)
 PSK_DECL_S(16)
 
 // S = 0: the channels that emit nothing this call.  Otherwise S in {2,3,4,5,6,7,8,10,12,16}, H in {1,2,4}
@@ -348,8 +353,13 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     PSK_CASE_S(6)
     PSK_CASE_S(7)
     PSK_CASE_S(8)
+    PSK_CASE_S(9)
     PSK_CASE_S(10)
+    PSK_CASE_S(11)
     PSK_CASE_S(12)
+    PSK_CASE_S(13)
+    PSK_CASE_S(14)
+    PSK_CASE_S(15)
     PSK_CASE_S(16)
     return hipErrorInvalidValue;
 }

@@ -268,6 +268,54 @@ def test_host_sized_energy_ring(oracle_mod):
         h.close()
 
 
+def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
+    """One instantiation of the wave-scan kernel per samplesPerBaud 2 .. 16 and window class (numAvg
+    <= 128 / <= 256 / <= 512): every one of them against the oracle, ragged packets, shaped and
+    rectangular pulses; samplesPerBaud 17 and 20 take the reference-order kernel."""
+    import random as _random
+
+    from psk_soft_amd.stimulus import gen_psk, synth_channel
+
+    rng = random.Random(31)
+    props, iqs, cuts = [], [], []
+    for S in list(range(2, 17)) + [17, 20]:
+        for A in (100, 200, 400):
+            M = rng.choice([2, 4, 8])
+            props.append(dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=rng.choice([10, 50, 200]),
+                              differentialDecoding=int(rng.random() < 0.2)))
+            N = S * (A + rng.choice([900, 1300]))
+            if rng.random() < 0.25:
+                iq, _ = gen_psk(N // S, samp_per_baud=S, num_syms=M, differential=False, rng=_random.Random(S * 1000 + A))
+                iq = np.asarray(iq, np.float32)
+            else:
+                iq = synth_channel(9000 + 16 * S + A, M, S, N, sigma=rng.choice([0.01, 0.1]))
+            iqs.append(iq)
+            cuts.append([0] + sorted(rng.sample(range(1, iq.size // 2), 2)) + [iq.size // 2])
+    n_ch = len(props)
+    h = _handle(n_ch, max_window_samples=20 * 400 + 64)
+    h.configure(0, props)
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
+    for k in range(3):
+        pk = [dict(data=iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], xdelta=0.01, sriChanged=(k == 0)) for c in range(n_ch)]
+        res = h.process_host(0, pk)
+        for c in range(n_ch):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    st = h.stats()
+    assert st["channels_sequential"] - st["channels_guard"] == 6, st  # samplesPerBaud 17 and 20, three windows each
+    for c in range(n_ch):
+        o = oracle_mod.OracleComponent()
+        for kk, v in props[c].items():
+            setattr(o, kk, v)
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(3):
+            r = o.service(iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, {k: np.concatenate(v) for k, v in ref.items()},
+                      "ch%d %s" % (c, props[c]))
+    h.close()
+
+
 def test_random_configuration_sweep(oracle_mod):
     """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
     and ragged packetisation, three calls each, every stream against the oracle: a broad net for
@@ -462,7 +510,7 @@ def test_property_changes_mid_stream(oracle_mod):
         ("push", take8(1000), dict(xdelta=1.0)),
         ("set", "samplesPerBaud", 10), ("set", "constelationSize", 8), ("set", "numAvg", 60),
         ("push", iq10[: 2 * 9000], {}),
-        ("set", "samplesPerBaud", 7), ("push", iq10[2 * 9000 : 2 * 14000], {}),   # no wave-scan instantiation
+        ("set", "samplesPerBaud", 7), ("push", iq10[2 * 9000 : 2 * 14000], {}),
         ("set", "samplesPerBaud", 1), ("push", iq10[2 * 14000 : 2 * 14500], {}),  # S == 1: nothing out (Q11)
         ("set", "numAvg", 0), ("push", iq10[2 * 14500 : 2 * 15000], {}),
         ("set", "resetState", 1), ("push", iq10[2 * 15000 : 2 * 15600], {}),      # S == 1, numAvg == 0: a symbol per sample
