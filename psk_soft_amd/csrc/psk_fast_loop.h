@@ -152,6 +152,32 @@ template <int S>
 PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long tau_lo, long long tau_hi, int lane,
                         float2 (&x)[kR][S])
 {
+    if constexpr (S % 2 == 1 && kR == 2) {
+        // odd samplesPerBaud: one symbol is an odd number of 8-byte samples, but a lane's TWO symbols are
+        // contiguous and 16*S bytes long: S 16-byte loads (at 8-byte alignment, which gfx950 global loads
+        // allow) instead of 2*S 8-byte ones, whenever both symbols are wanted and sit in the same buffer
+        const long long tau0 = cblk * kB + 2 * lane + (long long)A - 1;
+        const uint64_t j0 = (uint64_t)(tau0 > 0 ? tau0 : 0) * (uint64_t)S;
+        const bool both = tau0 >= tau_lo && tau0 + 1 <= tau_hi;
+        const bool in_pkt = j0 >= X.L0, in_ring = j0 + 2 * S <= X.L0;
+        if (both && (in_pkt || in_ring)) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+            const f4u *q = reinterpret_cast<const f4u *>(in_pkt ? X.in + (j0 - X.L0) : X.ring + j0);
+            float2 flat[2 * S];
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                const f4u t = q[k];
+                flat[2 * k] = make_float2(t.x, t.y);
+                flat[2 * k + 1] = make_float2(t.z, t.w);
+            }
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                x[0][k] = flat[k];
+                x[1][k] = flat[S + k];
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < kR; r++) {
         const long long tau = cblk * kB + 2 * lane + r + (long long)A - 1;
