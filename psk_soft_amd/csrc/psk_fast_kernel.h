@@ -16,8 +16,8 @@ PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 
 // nothing this call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
 // Register budget: the numAvg <= 128, samplesPerBaud <= 10 instantiations are held to 128 VGPRs
 // (4 waves per SIMD = 16 single-wave workgroups per CU, so a 4096-channel batch is resident at
-// once; samplesPerBaud = 10 pays for it with 11 spilled VGPRs and wins 20 % by the residency);
-// the others keep what they need.
+// once; samplesPerBaud = 9 and 10 pay for it with a handful of spilled VGPRs and win 20 % by the
+// residency); the others keep what they need.
 // Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
 // (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
 // runs on 1 and leaves 2.
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
                                                       uint32_t y_len, uint32_t r_len)
 {
     // LDS: [ring of unwrapped phases, a power of two >= phaseAvg + 128 floats][energy ring, numAvg <= 128
-    // only: SV rows].  Fixed sizes (512 floats, rows of 256) except samplesPerBaud = 10:
+    // only: SV rows].  Fixed sizes (512 floats, rows of 256) except samplesPerBaud = 9, 10:
     // dynamic LDS sized by the host for the launch (y_len floats, rows of r_len), see psk_fast_loop.h.
     constexpr bool kDyn = ering_dynamic(SV);
     float *yring;

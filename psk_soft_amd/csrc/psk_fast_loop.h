@@ -437,10 +437,8 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         if (!__any(bad))
             break;
         int w2[kR] = {w2_0, w2_1};
-#ifndef PSK_NO_REFINE
         if (!WARM)
             refine_unwrap(lane, n, est_prev0, est, rawd, valid, w, w2);
-#endif
         w[0] = w2[0];
         w[1] = w2[1];
         if (++pass > kMaxUnwrapPasses)
