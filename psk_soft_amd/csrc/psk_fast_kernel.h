@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
     float *yv = yvs + (size_t)ch * fit_cap;
 
     XView X;
-    X.ring = ring_src;
-    X.in = reinterpret_cast<const float2 *>(p.in);
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
     X.L0 = p.ring_len0;
 
     // ---- prologue: LinearFit history into the LDS ring; LinearFit::reset() sums if it ran ----

@@ -152,7 +152,7 @@ template <int S>
 PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long tau_lo, long long tau_hi, int lane,
                         float2 (&x)[kR][S])
 {
-    if constexpr (S % 2 == 1 && kR == 2) {
+    if constexpr (kR == 2 && S < 16) {
         // odd samplesPerBaud: one symbol is an odd number of 8-byte samples, but a lane's TWO symbols are
         // contiguous and 16*S bytes long: S 16-byte loads (at 8-byte alignment, which gfx950 global loads
         // allow) instead of 2*S 8-byte ones, whenever both symbols are wanted and sit in the same buffer
@@ -161,12 +161,12 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
         const bool both = tau0 >= tau_lo && tau0 + 1 <= tau_hi;
         const bool in_pkt = j0 >= X.L0, in_ring = j0 + 2 * S <= X.L0;
         if (both && (in_pkt || in_ring)) {
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-            const f4u *q = reinterpret_cast<const f4u *>(in_pkt ? X.in + (j0 - X.L0) : X.ring + j0);
+            const typename F4Ptr<packet_global(S)>::type q =
+                (typename F4Ptr<packet_global(S)>::type)(in_pkt ? X.in + (j0 - X.L0) : X.ring + j0);
             float2 flat[2 * S];
 #pragma unroll
             for (int k = 0; k < S; k++) {
-                const f4u t = q[k];
+                const f4g t = q[k];
                 flat[2 * k] = make_float2(t.x, t.y);
                 flat[2 * k + 1] = make_float2(t.z, t.w);
             }
@@ -613,6 +613,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     const int lane = threadIdx.x & 63;
     const uint32_t A = p.A, M = p.M, n = p.lf_n;
     const int n_out = (int)p.n_out;  // <= 2^20 on this path
+    // the caller's output rows (address space: see PSK_GLOBAL in psk_wave.h).  Not copied into locals:
+    // four pointers held across the loop are eight more scalar registers under pressure (measured
+    // +3 ... +6 % at samplesPerBaud 2 and 4); the plan is re-read where a store needs one.
+#define g_soft mem_ptr<packet_global(S)>(p.soft)
+#define g_phase mem_ptr<packet_global(S)>(p.phase)
+#define g_bits mem_ptr<packet_global(S)>(p.bits)
+#define g_sidx mem_ptr<packet_global(S)>(p.sidx)
     const float xd = p.lf_xdelta;
     const long long tau_last = (long long)n_out + (long long)A - 2;  // newest symbol any emitted window uses
 
@@ -885,12 +892,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         // sampleIndex_dataShort_out (reference cpp/psk_soft.cpp:466) --
         // after the re-read above, whose wait would otherwise also wait for this store
         if (p.sidx) {
-            typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
             if (valid[1]) {
                 s2u v = {(short)(unsigned short)bestK[0], (short)(unsigned short)bestK[1]};
-                *reinterpret_cast<s2u *>(p.sidx + i0) = v;
+                store_s2u(g_sidx + i0, v);
             } else if (valid[0]) {
-                p.sidx[i0] = (int16_t)(unsigned short)bestK[0];
+                g_sidx[i0] = (int16_t)(unsigned short)bestK[0];
             }
         }
 
@@ -968,56 +974,53 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             }
         }
         if (valid[1]) {
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-            typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
-            typedef short s4u __attribute__((ext_vector_type(4), aligned(4)));
             if (p.soft) {
                 f4u v = {corr[0].re, corr[0].im, corr[1].re, corr[1].im};
-                *reinterpret_cast<f4u *>(p.soft + 2 * (size_t)i0) = v;
+                store_f4u(g_soft + 2 * (size_t)i0, v);
             }
             if (p.phase) {
                 f2u v = {est[0], est[1]};
-                *reinterpret_cast<f2u *>(p.phase + i0) = v;
+                store_f2u(g_phase + i0, v);
             }
             if (!p.bits) {
             } else if (p.bpb == 1) {
                 s2u v = {(short)(corr[0].re < 0), (short)(corr[1].re < 0)};
-                *reinterpret_cast<s2u *>(p.bits + i0) = v;
+                store_s2u(g_bits + i0, v);
             } else if (p.bpb == 2) {  // quirk Q1 (float -> bool is "!= 0") unless the sign map was asked for
                 int a0, a1, b0, b1;
                 qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
                 qpsk_bits(corr[1].re, corr[1].im, qpsk_sign_map, b0, b1);
                 s4u v = {(short)a0, (short)a1, (short)b0, (short)b1};
-                *reinterpret_cast<s4u *>(p.bits + 2 * i0) = v;
+                store_s4u(g_bits + 2 * i0, v);
             } else if (p.bpb == 3) {
                 const unsigned short a = sym8[0], b = sym8[1];
                 s2u v0 = {(short)(a & 1), (short)((a >> 1) & 1)};
                 s2u v1 = {(short)((a >> 2) & 1), (short)(b & 1)};
                 s2u v2 = {(short)((b >> 1) & 1), (short)((b >> 2) & 1)};
-                s2u *q = reinterpret_cast<s2u *>(p.bits + 3 * i0);
-                q[0] = v0;
-                q[1] = v1;
-                q[2] = v2;
+                store_s2u(g_bits + 3 * i0, v0);
+                store_s2u(g_bits + 3 * i0 + 2, v1);
+                store_s2u(g_bits + 3 * i0 + 4, v2);
             }
         } else if (valid[0]) {  // an odd tail: one symbol
-            if (p.soft)
-                reinterpret_cast<float2 *>(p.soft)[i0] = make_float2(corr[0].re, corr[0].im);
+            if (p.soft) {
+                g_soft[2 * (size_t)i0] = corr[0].re;
+                g_soft[2 * (size_t)i0 + 1] = corr[0].im;
+            }
             if (p.phase)
-                p.phase[i0] = est[0];
+                g_phase[i0] = est[0];
             if (!p.bits) {
             } else if (p.bpb == 1) {
-                p.bits[i0] = (int16_t)(corr[0].re < 0);
+                g_bits[i0] = (int16_t)(corr[0].re < 0);
             } else if (p.bpb == 2) {
                 int a0, a1;
                 qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
-                p.bits[2 * i0] = (int16_t)a0;
-                p.bits[2 * i0 + 1] = (int16_t)a1;
+                g_bits[2 * i0] = (int16_t)a0;
+                g_bits[2 * i0 + 1] = (int16_t)a1;
             } else if (p.bpb == 3) {
                 const unsigned short a = sym8[0];
-                p.bits[3 * i0] = (int16_t)(a & 1);
-                p.bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
-                p.bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
+                g_bits[3 * i0] = (int16_t)(a & 1);
+                g_bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
+                g_bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
             }
         }
 
@@ -1074,5 +1077,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     }
 }
 
+#undef g_soft
+#undef g_phase
+#undef g_bits
+#undef g_sidx
 }  // namespace psk
 #endif

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
     const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
     float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
     XView X;
-    X.ring = ring_src;
-    X.in = reinterpret_cast<const float2 *>(p.in);
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
     X.L0 = p.ring_len0;
     const uint32_t S = p.S;
     const uint64_t N = p.n_in;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         if (p.mode != PLAN_SEQ_S1) {  // resyncEnergy ran in this call's prologue, :619-636
             for (uint32_t k = 0; k < S; k++) symE[k] = 0.0;
             for (uint64_t j = 0; j < X.L0; j++) {
-                float2 v = X.ring[j];
+                const float2 v = x_at(X, j);
                 symE[idx] += (double)norm_f(v.x, v.y);
                 idx++;
                 if (idx == S)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
     for (uint64_t base = 0; base < N; base += kSeqChunk) {
         const uint32_t cnt = (N - base) < (uint64_t)kSeqChunk ? (uint32_t)(N - base) : (uint32_t)kSeqChunk;
         __syncthreads();
-        for (uint32_t j = lane; j < cnt; j += kWave) chunk[j] = X.in[base + j];
+        for (uint32_t j = lane; j < cnt; j += kWave) chunk[j] = x_at(X, X.L0 + base + j);
         __syncthreads();
         if (lane == 0) {
             for (uint32_t jj = 0; jj < cnt; jj++) {

@@ -183,12 +183,63 @@ PSK_DEV void wave_lds_fence()
 // ---------------------------------------------------------------------------------
 // the virtual stream X = [ring of carried samples] ++ [packet]   (the `samples` deque)
 // ---------------------------------------------------------------------------------
+// Pointers that come out of a ChanPlan (packet, output rows) are generic to the compiler: it cannot
+// trace them to a kernel argument, and emits FLAT loads and stores for them.  A flat access counts on
+// vmcnt AND lgkmcnt, so a wait for an LDS result (energy ring, ds_bpermute, phase ring) also waits
+// for the packet loads in flight.  They are global memory (device or page-locked host), and the
+// wave-scan kernels say so (address space 1): -1 % at samplesPerBaud 8, -2 % at 6 and 10, -10 % at 12.
+// (packet_global(S) = false keeps an instantiation on generic accesses, for A/B runs.)
+#define PSK_GLOBAL __attribute__((address_space(1)))
+typedef float f2g __attribute__((ext_vector_type(2)));
+typedef float f4g __attribute__((ext_vector_type(4), aligned(8)));  // 16-byte access at 8-byte alignment
+constexpr bool packet_global(int) { return true; }
+template <bool G, class T>
+struct MemPtr {
+    typedef T *type;
+};
+template <class T>
+struct MemPtr<true, T> {
+    typedef PSK_GLOBAL T *type;
+};
+template <bool G, class T>
+PSK_DEV typename MemPtr<G, T>::type mem_ptr(T *p)
+{
+    return (typename MemPtr<G, T>::type)p;
+}
+// pointer to a 16-byte vector at 8-byte alignment, generic or global (spelled out: a template
+// parameter would drop the alignment attribute of the typedef)
+template <bool G>
+struct F4Ptr {
+    typedef const f4g *type;
+};
+template <>
+struct F4Ptr<true> {
+    typedef const PSK_GLOBAL f4g *type;
+};
+// vector stores to the output rows at the alignment the ABI asks for (soft 8, phase / bits /
+// sampleIndex 4 bytes), in the address space of the pointer
+typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef short s4u __attribute__((ext_vector_type(4), aligned(4)));
+PSK_DEV void store_f4u(float *p, f4u v) { *reinterpret_cast<f4u *>(p) = v; }
+PSK_DEV void store_f4u(PSK_GLOBAL float *p, f4u v) { *(PSK_GLOBAL f4u *)p = v; }
+PSK_DEV void store_f2u(float *p, f2u v) { *reinterpret_cast<f2u *>(p) = v; }
+PSK_DEV void store_f2u(PSK_GLOBAL float *p, f2u v) { *(PSK_GLOBAL f2u *)p = v; }
+PSK_DEV void store_s2u(int16_t *p, s2u v) { *reinterpret_cast<s2u *>(p) = v; }
+PSK_DEV void store_s2u(PSK_GLOBAL int16_t *p, s2u v) { *(PSK_GLOBAL s2u *)p = v; }
+PSK_DEV void store_s4u(int16_t *p, s4u v) { *reinterpret_cast<s4u *>(p) = v; }
+PSK_DEV void store_s4u(PSK_GLOBAL int16_t *p, s4u v) { *(PSK_GLOBAL s4u *)p = v; }
 struct XView {
-    const float2 *ring;
-    const float2 *in;
+    const f2g *ring;
+    const f2g *in;
     uint32_t L0;  // samples in the ring
 };
-PSK_DEV float2 x_at(const XView &X, uint64_t j) { return j < X.L0 ? X.ring[j] : X.in[j - X.L0]; }
+PSK_DEV float2 x_at(const XView &X, uint64_t j)
+{
+    const f2g v = j < X.L0 ? X.ring[j] : X.in[j - X.L0];
+    return make_float2(v.x, v.y);
+}
 
 template <int S>
 PSK_DEV void load_symbol(const XView &X, uint64_t tau, bool valid, float2 (&x)[S])
@@ -198,7 +249,7 @@ PSK_DEV void load_symbol(const XView &X, uint64_t tau, bool valid, float2 (&x)[S
     if (!valid)
         return;
     const uint64_t j0 = tau * (uint64_t)S;
-    const float2 *p;
+    const f2g *p;
     if (j0 >= X.L0) {
         p = X.in + (j0 - X.L0);
     } else if (j0 + S <= X.L0) {
@@ -210,17 +261,20 @@ PSK_DEV void load_symbol(const XView &X, uint64_t tau, bool valid, float2 (&x)[S
     }
     if (S % 2 == 0) {
         // 16-byte loads; the address is only 8-byte aligned (gfx950 global loads allow that)
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-        const f4u *q = reinterpret_cast<const f4u *>(p);
+        const typename F4Ptr<packet_global(S)>::type q = (typename F4Ptr<packet_global(S)>::type)p;
 #pragma unroll
         for (int k = 0; k < S / 2; k++) {
-            f4u t = q[k];
+            const f4g t = q[k];
             x[2 * k] = make_float2(t.x, t.y);
             x[2 * k + 1] = make_float2(t.z, t.w);
         }
     } else {
+        const auto q = mem_ptr<packet_global(S)>(p);
 #pragma unroll
-        for (int k = 0; k < S; k++) x[k] = p[k];
+        for (int k = 0; k < S; k++) {
+            const f2g t = q[k];
+            x[k] = make_float2(t.x, t.y);
+        }
     }
 }
 
