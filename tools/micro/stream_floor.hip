@@ -119,7 +119,7 @@ float run(const float* in, size_t row_floats, int n_blocks, float* soft, float* 
 
 int main()
 {
-    const int C = 4096; const size_t N = 1 << 18; const size_t row_floats = 2 * N; const size_t cap = N / 8 + 2; const int n_blocks = (int)(N / 8 / 128);
+    const int C = 4096; const size_t N = 1 << 18; const size_t row_floats = 2 * N; const size_t cap = (N / 8 + 2 + 63) / 64 * 64;  /* output rows on 128-byte boundaries, as bench.py lays them out */ const int n_blocks = (int)(N / 8 / 128);
     float *in, *soft, *phase; short *sidx, *bits;
     CHECK(hipMalloc(&in, sizeof(float) * row_floats * C)); CHECK(hipMemset(in, 0x3c, sizeof(float) * row_floats * C));
     CHECK(hipMalloc(&soft, sizeof(float) * 2 * cap * C)); CHECK(hipMalloc(&phase, sizeof(float) * cap * C));
