@@ -645,6 +645,70 @@ def test_zero_copy_from_pinned_host_memory(oracle_mod):
         pl.host_free(a.reshape(-1))
 
 
+def test_minimum_alignment_of_packets_and_outputs(oracle_mod):
+    """The ABI asks for 8-byte aligned packets and soft rows and 4-byte aligned bits / phase /
+    sampleIndex rows, no more.  The kernels fetch a lane's two symbols with 16-byte loads and write
+    16 / 8 / 4-byte vectors: every buffer here sits at exactly its minimum alignment (8 resp. 4 bytes
+    past a 16-byte boundary), in pinned host memory, for even and odd samplesPerBaud and two calls."""
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    cfgs = [(8, 4), (10, 8), (7, 2), (9, 4), (16, 4), (3, 8), (12, 2)]
+    n_ch, N = len(cfgs), 30000
+    iq_np = [synth_channel(8300 + c, M, S, N) for c, (S, M) in enumerate(cfgs)]
+    cap = N // 2 + 8
+    iq = pl.host_alloc(n_ch * (2 * N + 4), np.float32).reshape(n_ch, 2 * N + 4)
+    soft = pl.host_alloc(n_ch * (2 * cap + 4), np.float32).reshape(n_ch, 2 * cap + 4)
+    phase = pl.host_alloc(n_ch * (cap + 4), np.float32).reshape(n_ch, cap + 4)
+    sidx = pl.host_alloc(n_ch * (cap + 8), np.int16).reshape(n_ch, cap + 8)
+    bits = pl.host_alloc(n_ch * (3 * cap + 8), np.int16).reshape(n_ch, 3 * cap + 8)
+    h = pl.Handle(n_ch, device=0)
+    h.configure(0, [dict(samplesPerBaud=S, constelationSize=M) for S, M in cfgs])
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
+    cuts = [0, 13001, N]
+    for k in range(2):
+        pk = (pl.Packet * n_ch)()
+        out = (pl.Output * n_ch)()
+        for c in range(n_ch):
+            n_c = cuts[k + 1] - cuts[k]
+            iq[c, 2 : 2 + 2 * n_c] = iq_np[c][2 * cuts[k] : 2 * cuts[k + 1]]
+            pk[c].data = iq[c].ctypes.data + 8
+            assert pk[c].data % 16 == 8
+            pk[c].n_floats = 2 * n_c
+            pk[c].sri_xdelta = 0.01
+            pk[c].sri_mode = 1
+            pk[c].sriChanged = int(k == 0)
+            pk[c].present = 1
+            out[c].soft = soft[c].ctypes.data + 8
+            out[c].bits = bits[c].ctypes.data + 4
+            out[c].phase = phase[c].ctypes.data + 4
+            out[c].sampleIndex = sidx[c].ctypes.data + 4
+            assert out[c].soft % 16 == 8 and out[c].bits % 8 == 4 and out[c].phase % 8 == 4 and out[c].sampleIndex % 8 == 4
+            out[c].cap_symbols = cap
+        h.process_device(0, pk, out)
+        h.synchronize()
+        for c in range(n_ch):
+            n = int(out[c].n_symbols)
+            got[c]["soft"].append(soft[c, 2 : 2 + 2 * n].copy())
+            got[c]["phase"].append(phase[c, 1 : 1 + n].copy())
+            got[c]["bits"].append(bits[c, 2 : 2 + int(out[c].n_bits)].copy())
+            got[c]["index"].append(sidx[c, 2 : 2 + int(out[c].n_sampleIndex)].copy())
+    assert h.stats()["channels_sequential"] == 0
+    for c, (S, M) in enumerate(cfgs):
+        o = oracle_mod.OracleComponent()
+        o.samplesPerBaud = S
+        o.constelationSize = M
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(2):
+            r = o.service(iq_np[c][2 * cuts[k] : 2 * cuts[k + 1]], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, {k: np.concatenate(v) for k, v in ref.items()},
+                      "S=%d M=%d" % (S, M))
+    h.close()
+    for a in (iq, soft, phase, sidx, bits):
+        pl.host_free(a.reshape(-1))
+
+
 @pytest.mark.parametrize("force_seq", [0, 1])
 def test_opt_in_qpsk_sign_bitmap(oracle_mod, force_seq):
     """PSK_SOFT_OPT_QPSK_SIGN_BITMAP: QPSK bits follow the signs of the de-rotated symbol (the
