@@ -1,5 +1,6 @@
 """Per-launch duration of the headline configuration over a long run of back-to-back steps (diagnostic:
-how long the first-launches ramp of a fresh process lasts).  usage (GPU box): python tools/launch_ramp.py [steps]"""
+how long the first-launches ramp of a fresh process lasts, and whether it is the GPU waking up -- [probe passes]
+of another kernel right before the run -- or this kernel warming up).  usage (GPU box): python tools/launch_ramp.py [steps] [probe passes]"""
 import os
 import sys
 
@@ -28,6 +29,9 @@ for c in range(C):
 h = pl.Handle(C, device=0)
 h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=50)
 stream = torch.cuda.Stream(device=dev)
+pre = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # passes of the pure-read probe right before (a busy GPU, another kernel)
+if pre:
+    print("probe pass before the run: %.3f ms" % h.probe_read_ms(iq.data_ptr(), iq.numel() * 4, reps=pre))
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
 ev[0].record(stream)
