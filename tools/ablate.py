@@ -25,9 +25,9 @@ for sec in sys.argv[1:]:
         swap("cf32 pw = cpow_uint<false>(s[r], M);", "cf32 pw = s[r];")
     elif sec == "fit":
         swap(
-            "        if (!EXACT || __builtin_expect(q0 >= n, 1)) {\n            pass = fit_block<false>(",
+            "        if (__builtin_expect(q0 >= n, 1)) {\n            pass = fit_block<false>(",
             "        if (true) { pass = 0;\n#pragma unroll\n for (int r = 0; r < kR; r++) { y[r] = (float)rawd[r]; est[r] = y[r]; "
-            "ySum_l[r] = rawd[r]; xySum_l[r] = rawd[r]; }\n } else if (!EXACT || __builtin_expect(q0 >= n, 1)) {\n"
+            "ySum_l[r] = rawd[r]; xySum_l[r] = rawd[r]; }\n } else if (__builtin_expect(q0 >= n, 1)) {\n"
             "            pass = fit_block<false>(",
         )
     elif sec == "scan":
@@ -35,7 +35,7 @@ for sec in sys.argv[1:]:
     elif sec == "argmax":
         swap("                    m2[0] = med3_i32(m1[0], m2[0], p0);\n                    m2[1] = med3_i32(m1[1], m2[1], p1);\n", "")
     elif sec == "out":
-        swap("        if (valid[1]) {\n            typedef float f4u", "        if (false) {\n            typedef float f4u")
+        swap("        if (valid[1]) {\n            if (p.soft) {", "        if (false) {\n            if (p.soft) {")
     elif sec == "rot":
         swap("    return bperm_addr(p.src_addr[r], offered);", "    return offered;")
     else:

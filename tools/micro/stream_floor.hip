@@ -117,9 +117,74 @@ float run(const float* in, size_t row_floats, int n_blocks, float* soft, float* 
     return ms / reps;
 }
 
-int main()
+// the same traffic with the NEXT block's loads issued before the current block is consumed (two blocks
+// of a wave in flight): does the floor move with more bytes in flight per wave?
+template <bool STORES>
+__global__ __launch_bounds__(64) void k_stream_prefetch(const float* __restrict__ in, size_t row_floats, int n_blocks,
+                                                        float* __restrict__ soft, float* __restrict__ phase,
+                                                        short* __restrict__ sidx, short* __restrict__ bits, size_t cap)
 {
-    const int C = 4096; const size_t N = 1 << 18; const size_t row_floats = 2 * N; const size_t cap = (N / 8 + 2 + 63) / 64 * 64;  /* output rows on 128-byte boundaries, as bench.py lays them out */ const int n_blocks = (int)(N / 8 / 128);
+    const int lane = threadIdx.x;
+    const float* row = in + (size_t)blockIdx.x * row_floats;
+    float* so = soft + (size_t)blockIdx.x * 2 * cap;
+    float* ph = phase + (size_t)blockIdx.x * cap;
+    short* sx = sidx + (size_t)blockIdx.x * cap;
+    short* bi = bits + (size_t)blockIdx.x * 2 * cap;
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef short s4u __attribute__((ext_vector_type(4), aligned(4)));
+    float acc = 0.f;
+    f4u cur[8], nxt[8];
+    {
+        const f4u* src = reinterpret_cast<const f4u*>(row);
+#pragma unroll
+        for (int j = 0; j < 8; j++) cur[j] = src[lane * 8 + j];
+    }
+    for (int c = 0; c < n_blocks; c++) {
+        if (c + 1 < n_blocks) {
+            const f4u* src = reinterpret_cast<const f4u*>(row + (size_t)(c + 1) * 2048);
+#pragma unroll
+            for (int j = 0; j < 8; j++) nxt[j] = src[lane * 8 + j];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += cur[j].x * cur[j].y + cur[j].z * cur[j].w;
+        acc += s;
+        if (STORES) {
+            const size_t i0 = (size_t)c * 128 + 2 * lane;
+            f4u v = {s, acc, s, acc};
+            *reinterpret_cast<f4u*>(so + 2 * i0) = v;
+            f2u p2 = {s, acc};
+            *reinterpret_cast<f2u*>(ph + i0) = p2;
+            s2u x2 = {(short)(s > 0), (short)(acc > 0)};
+            *reinterpret_cast<s2u*>(sx + i0) = x2;
+            s4u b4 = {(short)(s > 0), 0, (short)(acc > 0), 0};
+            *reinterpret_cast<s4u*>(bi + 2 * i0) = b4;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+    }
+    if (acc == 12345.678f) so[0] = acc;
+}
+
+template <bool STORES>
+float run_prefetch(const float* in, size_t row_floats, int n_blocks, float* soft, float* phase, short* sidx, short* bits, size_t cap, int C)
+{
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL(k_stream_prefetch<STORES>, dim3(C), dim3(64), 0, 0, in, row_floats, n_blocks, soft, phase, sidx, bits, cap);
+    CHECK(hipEventRecord(a));
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_stream_prefetch<STORES>, dim3(C), dim3(64), 0, 0, in, row_floats, n_blocks, soft, phase, sidx, bits, cap);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    // argv[1]: extra symbols of padding per output row (a multiple of 64 keeps the rows on 128-byte boundaries); argv[2] = 1: floor lines only
+    const size_t pad = argc > 1 ? (size_t)atol(argv[1]) : 0; const bool quick = argc > 2 && atoi(argv[2]) != 0;
+    const int C = 4096; const size_t N = 1 << 18; const size_t row_floats = 2 * N; const size_t cap = (N / 8 + 2 + 63) / 64 * 64 + pad;  /* output rows on 128-byte boundaries, as bench.py lays them out */ const int n_blocks = (int)(N / 8 / 128);
     float *in, *soft, *phase; short *sidx, *bits;
     CHECK(hipMalloc(&in, sizeof(float) * row_floats * C)); CHECK(hipMemset(in, 0x3c, sizeof(float) * row_floats * C));
     CHECK(hipMalloc(&soft, sizeof(float) * 2 * cap * C)); CHECK(hipMalloc(&phase, sizeof(float) * cap * C));
@@ -127,6 +192,7 @@ int main()
     const double rd = 8.0 * N * C, wr = (double)C * (N / 8) * 18.0;
     float ms;
     ms = run<0>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode0 lane-contiguous loads + 4 stores : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    if (quick) { printf("   in %p soft %p phase %p sidx %p bits %p cap %zu\n", (void*)in, (void*)soft, (void*)phase, (void*)sidx, (void*)bits, cap); return 0; }
     ms = run<1>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode1 wave-coalesced loads + 4 stores  : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<2>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode2 lane-contiguous loads only        : %.3f ms  read %.2f TB/s\n", ms, rd / ms / 1e9);
     ms = run<3>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode3 wave-coalesced loads only         : %.3f ms  read %.2f TB/s\n", ms, rd / ms / 1e9);
@@ -135,6 +201,8 @@ int main()
     ms = run<6>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode6 nontemporal loads and stores       : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<7>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode7 narrow streams batched x4          : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
     ms = run<8>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode8 narrow streams batched x2 (pairs)   : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    ms = run_prefetch<true>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode0 with the next block prefetched   : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
+    ms = run_prefetch<false>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode2 with the next block prefetched   : %.3f ms  read %.2f TB/s\n", ms, rd / ms / 1e9);
     ms = run<0>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode0 again                              : %.3f ms\n", ms);
     // does the power-of-two row stride of the input (2 MiB per channel) matter?  same kernels, padded rows
     CHECK(hipFree(in));
