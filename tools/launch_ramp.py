@@ -1,6 +1,13 @@
 """Per-launch duration of the headline configuration over a long run of back-to-back steps (diagnostic:
-how long the first-launches ramp of a fresh process lasts, and whether it is the GPU waking up -- [probe passes]
-of another kernel right before the run -- or this kernel warming up).  usage (GPU box): python tools/launch_ramp.py [steps] [probe passes]"""
+how long the first-launches ramp of a fresh process lasts, and what it is).
+
+usage (GPU box): python tools/launch_ramp.py [steps] [probe passes] [zero|other]
+  probe passes: that many passes of the pure-read probe kernel right before the run (a busy GPU, another kernel)
+  zero:         the output rows written once by another kernel before the run
+  other:        ten launches of the same kernels on other channel state and other output rows before the run
+Measured: the first ten launches run 10-12 % slower; neither a busy GPU nor touched output pages change that,
+ten launches of the same kernels elsewhere remove it (2.60 -> 2.37 ms for steps 0-9): it is the GPU settling
+on this instruction mix, i.e. warm-up proper."""
 import os
 import sys
 
@@ -32,6 +39,20 @@ stream = torch.cuda.Stream(device=dev)
 pre = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # passes of the pure-read probe right before (a busy GPU, another kernel)
 if pre:
     print("probe pass before the run: %.3f ms" % h.probe_read_ms(iq.data_ptr(), iq.numel() * 4, reps=pre))
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+if mode == "zero":  # the output rows written once by another kernel before the run
+    for t in (soft, phase, sidx, bits):
+        t.zero_()
+if mode == "other":  # ten launches of the same kernels on OTHER channels' state and other output rows first
+    h2 = pl.Handle(C, device=0)
+    h2.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=50)
+    soft2, phase2, sidx2, bits2 = (torch.empty_like(t) for t in (soft, phase, sidx, bits))
+    out2 = (pl.Output * C)()
+    for c in range(C):
+        out2[c].soft = soft2[c].data_ptr(); out2[c].bits = bits2[c].data_ptr(); out2[c].phase = phase2[c].data_ptr()
+        out2[c].sampleIndex = sidx2[c].data_ptr(); out2[c].cap_symbols = cap
+    for _ in range(10):
+        h2.process_device(0, pk, out2, stream=stream.cuda_stream)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
 ev[0].record(stream)
