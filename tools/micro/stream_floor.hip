@@ -186,9 +186,20 @@ int main(int argc, char **argv)
     const size_t pad = argc > 1 ? (size_t)atol(argv[1]) : 0; const bool quick = argc > 2 && atoi(argv[2]) != 0;
     const int C = 4096; const size_t N = 1 << 18; const size_t row_floats = 2 * N; const size_t cap = (N / 8 + 2 + 63) / 64 * 64 + pad;  /* output rows on 128-byte boundaries, as bench.py lays them out */ const int n_blocks = (int)(N / 8 / 128);
     float *in, *soft, *phase; short *sidx, *bits;
+    const bool one_block = argc > 3 && atoi(argv[3]) != 0;  // argv[3] = 1: all five buffers carved out of ONE allocation
+    if (one_block) {
+        const size_t b_in = sizeof(float) * row_floats * C, b_soft = sizeof(float) * 2 * cap * C, b_ph = sizeof(float) * cap * C,
+                     b_sx = sizeof(short) * cap * C, b_bi = sizeof(short) * 2 * cap * C;
+        auto up = [](size_t v) { return (v + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); };
+        char *blk; CHECK(hipMalloc(&blk, up(b_in) + up(b_soft) + up(b_ph) + up(b_sx) + up(b_bi)));
+        in = (float *)blk; soft = (float *)(blk + up(b_in)); phase = (float *)((char *)soft + up(b_soft));
+        sidx = (short *)((char *)phase + up(b_ph)); bits = (short *)((char *)sidx + up(b_sx));
+        CHECK(hipMemset(in, 0x3c, b_in));
+    } else {
     CHECK(hipMalloc(&in, sizeof(float) * row_floats * C)); CHECK(hipMemset(in, 0x3c, sizeof(float) * row_floats * C));
     CHECK(hipMalloc(&soft, sizeof(float) * 2 * cap * C)); CHECK(hipMalloc(&phase, sizeof(float) * cap * C));
     CHECK(hipMalloc(&sidx, sizeof(short) * cap * C)); CHECK(hipMalloc(&bits, sizeof(short) * 2 * cap * C));
+    }
     const double rd = 8.0 * N * C, wr = (double)C * (N / 8) * 18.0;
     float ms;
     ms = run<0>(in, row_floats, n_blocks, soft, phase, sidx, bits, cap, C); printf("mode0 lane-contiguous loads + 4 stores : %.3f ms  read %.2f TB/s total %.2f TB/s\n", ms, rd / ms / 1e9, (rd + wr) / ms / 1e9);
