@@ -146,6 +146,7 @@ struct PlanSummary {
     // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
     // ring of r_len positions (even, >= numAvg + 128)
     uint32_t max_n[17][5] = {}, max_A[17][5] = {};
+    uint32_t max_n_quiet = 0;  // ... and of the channels that emit nothing this call
 };
 
 // One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
@@ -170,7 +171,7 @@ inline size_t region_bits(size_t in_cap) { return in_cap + in_cap + in_cap / 2; 
 inline size_t region_sidx(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap; }
 inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap + in_cap / 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr uint32_t kFastFitMax = 384;  // LDS y ring of the wave-scan kernel: 512 - 128
+constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 
@@ -421,6 +422,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                     if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
                 } else {
                     r.any_quiet = true;
+                    if (p.lf_n > r.max_n_quiet) r.max_n_quiet = p.lf_n;
                 }
             } else {
                 r.any_seq = true;
@@ -462,16 +464,23 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     h->slot = (h->slot + 1) % kPlanSlots;
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
                            stream));
+    // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
+    // the energy ring is dynamic too and every byte of LDS counts towards residency)
+    auto ring_floats = [](uint32_t n_max, uint32_t at_least) {
+        uint32_t y = at_least;
+        while (y < n_max + 128u) y <<= 1;
+        return y;
+    };
     if (any_quiet)
         PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                 h->lim.fit_cap, kFastFitMax + 128u, 0u, stream));
+                                 h->lim.fit_cap, ring_floats(res.max_n_quiet, 512u), 0u, stream));
     // screened timing first; the exact-timing instantiation picks up the calls it refused, the
     // reference-order kernel (below) the calls both refused
     for (int exact = 0; exact <= 1; exact++)
         for (int S : kFastS)
             for (int H = exact ? 2 : 1; H <= 4; H++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
                 if (need_SH[S][H]) {
-                    const uint32_t y_len = max_n[S][H] + 128u <= 256u ? 256u : 512u;
+                    const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
                     const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
                     PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
                                              h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, stream));

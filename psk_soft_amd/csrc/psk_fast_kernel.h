@@ -27,24 +27,20 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)
 {
-    // LDS: [ring of unwrapped phases, a power of two >= phaseAvg + 128 floats][energy ring, numAvg <= 128
-    // only: SV rows].  Fixed sizes (512 floats, rows of 256) except samplesPerBaud = 9, 10:
-    // dynamic LDS sized by the host for the launch (y_len floats, rows of r_len), see psk_fast_loop.h.
+    // LDS: a ring of the last unwrapped phases (y_len floats, a power of two >= phaseAvg + 128 for every
+    // channel of the launch, sized by the host: dynamic LDS) and, for numAvg <= 128, the energy ring of
+    // SV rows -- 256 positions each, static, except samplesPerBaud = 9, 10 where the rows follow the
+    // phase ring in the dynamic segment at r_len positions each (see psk_fast_loop.h).
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     constexpr bool kDyn = ering_dynamic(SV);
-    float *yring;
-    uint32_t ymask;
+    float *const yring = lds_dyn;
+    const uint32_t ymask = y_len - 1u;
     ERingT<kDyn> er;
     if constexpr (kDyn) {
-        extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-        yring = lds_dyn;
-        ymask = y_len - 1u;
         er.mem = lds_dyn + y_len;
         er.set_len((int)r_len);
     } else {
-        __shared__ float yring_s[kYRing];
         __shared__ __attribute__((aligned(16))) float ering_s[(SV != 0 && HV == 1) ? SV * kERing : 4];
-        yring = yring_s;
-        ymask = kYMask;
         er.mem = ering_s;
     }
     const int lane = threadIdx.x & 63;
@@ -194,7 +190,7 @@ hipError_t launch_fast_inst(PSK_FAST_ARGS)
 {
     if (!nch)
         return hipSuccess;
-    const size_t lds_bytes = ering_dynamic(SV) ? sizeof(float) * ((size_t)y_len + (size_t)SV * r_len) : 0;
+    const size_t lds_bytes = sizeof(float) * ((size_t)y_len + (ering_dynamic(SV) ? (size_t)SV * r_len : 0));
     hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, ch0, states,
                        rings, ring_cap, yvs, fit_cap, y_len, r_len);
     return hipGetLastError();

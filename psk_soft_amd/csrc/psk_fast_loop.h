@@ -219,7 +219,6 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
 //   instead of a mask, which costs where residency is not the limit (S = 8: +1.5 %, S = 12: +7 %,
 //   S = 16: -1 %), hence only there.
 constexpr int kERing = 2 * kB;
-constexpr bool ering_dynamic(int S) { return S == 9 || S == 10; }
 template <bool DYN>
 struct ERingT;
 template <>

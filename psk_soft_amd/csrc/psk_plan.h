@@ -29,6 +29,10 @@ enum LfFlags : uint32_t {
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582
 
+// wave-scan kernel, numAvg <= 128: the instantiations whose LDS energy ring is sized by the host per
+// launch (psk_fast_loop.h) instead of the fixed 256 positions -- the host sizes their phase ring tighter too
+constexpr bool ering_dynamic(int S) { return S == 9 || S == 10; }
+
 struct ChanPlan {
     // data (device pointers)
     const float *in;   // packet: interleaved I,Q

@@ -12,8 +12,8 @@
 namespace psk {
 
 constexpr int kWave = 64;
-constexpr int kYRing = 512;         // LDS ring of unwrapped phases per wave (floats)
-constexpr int kYMask = kYRing - 1;
+constexpr int kYRingMin = 512;      // LDS ring of unwrapped phases per wave (floats): the host picks a power of
+constexpr int kYRingMax = 2048;     // two >= phaseAvg + 128 in this range (256 allowed where the energy ring is dynamic too)
 constexpr int kSeqMaxS = 1024;      // reference-order kernel: symbolEnergy[] lives in LDS
 constexpr int kSeqChunk = 512;      // reference-order kernel: packet staging chunk (complex samples)
 

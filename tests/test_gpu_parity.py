@@ -316,6 +316,44 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     h.close()
 
 
+def test_long_phase_averages_stay_on_the_wave_scan_kernel(oracle_mod):
+    """The LDS ring of unwrapped phases is sized by the host per launch (a power of two >= phaseAvg + 128, up
+    to 2048 floats): phaseAvg up to 1920 runs on the wave-scan kernel (it was 384), beyond that on the
+    reference-order kernel.  Mixed in one batch, ragged packets, a window that is still filling at first."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    rng = random.Random(41)
+    cfgs = [(8, 4, 385), (8, 2, 500), (10, 8, 1000), (8, 4, 1920), (4, 4, 700), (16, 2, 450), (10, 4, 50), (8, 4, 1921), (7, 8, 3000)]
+    props, iqs, cuts = [], [], []
+    for c, (S, M, n) in enumerate(cfgs):
+        props.append(dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n))
+        N = S * 6000
+        iqs.append(synth_channel(9500 + c, M, S, N, sigma=(0.01, 0.1)[c % 2]))
+        cuts.append([0] + sorted(rng.sample(range(1, N), 2)) + [N])
+    h = _handle(len(cfgs), max_phase_avg=4096)
+    h.configure(0, props)
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in cfgs]
+    for k in range(3):
+        pk = [dict(data=iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], xdelta=0.01, sriChanged=(k == 0)) for c in range(len(cfgs))]
+        res = h.process_host(0, pk)
+        for c in range(len(cfgs)):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    st = h.stats()
+    assert st["channels_sequential"] - st["channels_guard"] == 2, st  # phaseAvg 1921 and 3000
+    for c in range(len(cfgs)):
+        o = oracle_mod.OracleComponent()
+        for kk, v in props[c].items():
+            setattr(o, kk, v)
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(3):
+            r = o.service(iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, {k: np.concatenate(v) for k, v in ref.items()},
+                      "ch%d %s" % (c, props[c]))
+    h.close()
+
+
 def test_random_configuration_sweep(oracle_mod):
     """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
     and ragged packetisation, three calls each, every stream against the oracle: a broad net for

@@ -75,7 +75,7 @@ def main():
             S = rng.choice([2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 17])
             A = rng.choice([1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520])
             M = rng.choice([2, 4, 4, 8])
-            n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400])
+            n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400, 900, 1920, 1921])
             p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
             N = max(S * rng.choice([50, 300, 1200, 3000, 12000]), 64)
             sig = make_signal(rng, nrng, M, max(S, 1), N)
@@ -95,7 +95,7 @@ def main():
             props.append(p)
             sigs.append(sig)
             scripts.append(ev)
-        h = pl.Handle(C, device=0, max_window_samples=17 * 520 + 64, max_phase_avg=512)
+        h = pl.Handle(C, device=0, max_window_samples=17 * 520 + 64, max_phase_avg=2048)
         h.configure(0, props)
         oracles = []
         for c in range(C):
