@@ -141,11 +141,11 @@ struct PlanSummary {
     uint32_t bad = 0;  // first refused channel (index into the batch)
     int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
-    bool need_SH[17][5] = {};
+    bool need_SH[33][5] = {};
     // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
     // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
     // ring of r_len positions (even, >= numAvg + 128)
-    uint32_t max_n[17][5] = {}, max_A[17][5] = {};
+    uint32_t max_n[33][5] = {}, max_A[33][5] = {};
     uint32_t max_n_quiet = 0;  // ... and of the channels that emit nothing this call
 };
 
@@ -173,7 +173,7 @@ inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
-const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 32};
 
 }  // namespace
 

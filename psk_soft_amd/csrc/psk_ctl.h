@@ -73,12 +73,14 @@ struct Limits {
     bool force_seq;
 };
 
-// instantiations of the wave-scan kernel: samplesPerBaud 2 .. 16, numAvg <= 512
-// (window history of ceil(numAvg/128) <= 4 blocks in registers)
+// instantiations of the wave-scan kernel: samplesPerBaud 2 .. 16 with numAvg <= 512 (window history of
+// ceil(numAvg/128) <= 4 blocks in registers), samplesPerBaud 20, 24 and 32 with numAvg <= 256
 constexpr uint32_t kFastMaxNumAvg = 512;
-inline bool fast_kernel_has_S(uint32_t S)
+inline bool fast_kernel_has(uint32_t S, uint32_t A)
 {
-    return S >= 2 && S <= 16;
+    if (S >= 2 && S <= 16)
+        return A <= kFastMaxNumAvg;
+    return (S == 20 || S == 24 || S == 32) && A <= 256u;
 }
 
 // LinearFit::reset(numPts, sampleRate, forceHistoryClear) on the control state,
@@ -243,8 +245,8 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         c.index = c.ring_len % S;
         c.count = (c.count + n_out) % kResyncCount;  // :581-583
         plan.ring_len1 = (uint32_t)c.ring_len;
-        bool fast_ok = !lim.force_seq && fast_kernel_has_S((uint32_t)S) && c.lf_n <= lim.fast_fit_max &&
-                       n_out <= kResyncCount && A <= kFastMaxNumAvg &&
+        bool fast_ok = !lim.force_seq && fast_kernel_has((uint32_t)S, (uint32_t)A) && c.lf_n <= lim.fast_fit_max &&
+                       n_out <= kResyncCount &&
                        ((plan_lf_count0(c)) + n_out <= kResyncCount);
         plan.mode = (n_out == 0 || fast_ok) ? PLAN_FAST : PLAN_SEQ;
         if (lim.force_seq && n_out > 0)

@@ -142,7 +142,7 @@ PSK_DEV float sel_tree(const float2 (&x)[S], int k, bool want_y)
 template <int S>
 PSK_DEV float2 select_sample(const float2 (&x)[S], int k)
 {
-    constexpr int P = S <= 2 ? 2 : S <= 4 ? 4 : S <= 8 ? 8 : 16;
+    constexpr int P = S <= 2 ? 2 : S <= 4 ? 4 : S <= 8 ? 8 : S <= 16 ? 16 : 32;
     return make_float2(sel_tree<S, 0, P>(x, k, false), sel_tree<S, 0, P>(x, k, true));
 }
 
@@ -794,7 +794,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             // a median-of-three chain the runner-up.  Dropping the sign and overwriting IB low
             // bits moves a value by at most 2*E + 2^IB ulp; the acceptance threshold below
             // absorbs that.  A NaN anywhere has the largest pattern and fails the test.
-            constexpr int IB = S <= 2 ? 1 : S <= 4 ? 2 : S <= 8 ? 3 : 4;
+            constexpr int IB = S <= 2 ? 1 : S <= 4 ? 2 : S <= 8 ? 3 : S <= 16 ? 4 : 5;
             constexpr int IMASK = (1 << IB) - 1;
             float inc[S], d1v[S];
 #pragma unroll
