@@ -66,8 +66,11 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     C = int(sys.argv[2]) if len(sys.argv) > 2 else 192
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    only = int(sys.argv[4]) if len(sys.argv) > 4 else None  # replay one round (each round draws from its own generator)
     bad_total = 0
     for rnd in range(rounds):
+        if only is not None and rnd != only:
+            continue
         rng = random.Random(seed * 1000 + rnd)
         nrng = np.random.default_rng(seed * 1000 + rnd)
         props, sigs, scripts = [], [], []
@@ -153,6 +156,16 @@ def main():
             if why:
                 bad += 1
                 print("MISMATCH round %d channel %d: %s  props=%s script=%s" % (rnd, c, why, props[c], scripts[c]))
+                if g["phase"].size == r["phase"].size and g["soft"].size == r["soft"].size and g["phase"].size:
+                    # where, and what the phase estimate is there: one ulp of a large estimate is the known case
+                    dp = np.nonzero(g["phase"] != r["phase"])[0]
+                    ds = np.nonzero(g["soft"] != r["soft"])[0]
+                    print("   phase: %d of %d values differ%s; soft: %d floats differ; max |phase| %.1f"
+                          % (dp.size, g["phase"].size,
+                             "" if not dp.size else " (first at %d: %.9g vs %.9g, %d ulp)" % (
+                                 dp[0], g["phase"][dp[0]], r["phase"][dp[0]],
+                                 abs(int(g["phase"][dp[0]:dp[0] + 1].view(np.int32)[0]) - int(r["phase"][dp[0]:dp[0] + 1].view(np.int32)[0]))),
+                             ds.size, float(np.abs(r["phase"][np.isfinite(r["phase"])]).max())))
         bad_total += bad
         print("round %d: %d channels, %d mismatches, last-call stats %s" % (rnd, C, bad, st))
     print("TOTAL mismatches:", bad_total)
