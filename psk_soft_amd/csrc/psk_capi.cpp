@@ -173,7 +173,8 @@ inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
-const int kFastS[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 32};
+const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                      18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
 
 }  // namespace
 

@@ -74,13 +74,13 @@ struct Limits {
 };
 
 // instantiations of the wave-scan kernel: samplesPerBaud 2 .. 16 with numAvg <= 512 (window history of
-// ceil(numAvg/128) <= 4 blocks in registers), samplesPerBaud 20, 24 and 32 with numAvg <= 256
+// ceil(numAvg/128) <= 4 blocks in registers), samplesPerBaud 17 .. 32 with numAvg <= 256
 constexpr uint32_t kFastMaxNumAvg = 512;
 inline bool fast_kernel_has(uint32_t S, uint32_t A)
 {
     if (S >= 2 && S <= 16)
         return A <= kFastMaxNumAvg;
-    return (S == 20 || S == 24 || S == 32) && A <= 256u;
+    return S <= 32 && A <= 256u;
 }
 
 // LinearFit::reset(numPts, sampleRate, forceHistoryClear) on the control state,

@@ -331,8 +331,21 @@ PSK_DECL_S(14)
 PSK_DECL_S(15)
 PSK_DECL_S(16)
 #define PSK_DECL_S_WIDE(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2)
+PSK_DECL_S_WIDE(17)
+PSK_DECL_S_WIDE(18)
+PSK_DECL_S_WIDE(19)
 PSK_DECL_S_WIDE(20)
+PSK_DECL_S_WIDE(21)
+PSK_DECL_S_WIDE(22)
+PSK_DECL_S_WIDE(23)
 PSK_DECL_S_WIDE(24)
+PSK_DECL_S_WIDE(25)
+PSK_DECL_S_WIDE(26)
+PSK_DECL_S_WIDE(27)
+PSK_DECL_S_WIDE(28)
+PSK_DECL_S_WIDE(29)
+PSK_DECL_S_WIDE(30)
+PSK_DECL_S_WIDE(31)
 PSK_DECL_S_WIDE(32)
 
 // S = 0: the channels that emit nothing this call.  Otherwise S in {2,3,4,5,6,7,8,10,12,16}, H in {1,2,4}
@@ -366,8 +379,21 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     PSK_CASE_S(15)
     PSK_CASE_S(16)
 #define PSK_CASE_S_WIDE(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2)
+    PSK_CASE_S_WIDE(17)
+    PSK_CASE_S_WIDE(18)
+    PSK_CASE_S_WIDE(19)
     PSK_CASE_S_WIDE(20)
+    PSK_CASE_S_WIDE(21)
+    PSK_CASE_S_WIDE(22)
+    PSK_CASE_S_WIDE(23)
     PSK_CASE_S_WIDE(24)
+    PSK_CASE_S_WIDE(25)
+    PSK_CASE_S_WIDE(26)
+    PSK_CASE_S_WIDE(27)
+    PSK_CASE_S_WIDE(28)
+    PSK_CASE_S_WIDE(29)
+    PSK_CASE_S_WIDE(30)
+    PSK_CASE_S_WIDE(31)
     PSK_CASE_S_WIDE(32)
     return hipErrorInvalidValue;
 }
