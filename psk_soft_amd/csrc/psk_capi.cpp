@@ -141,11 +141,11 @@ struct PlanSummary {
     uint32_t bad = 0;  // first refused channel (index into the batch)
     int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
-    bool need_SH[33][5] = {};
+    bool need_SH[33][9] = {};
     // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
     // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
     // ring of r_len positions (even, >= numAvg + 128)
-    uint32_t max_n[33][5] = {}, max_A[33][5] = {};
+    uint32_t max_n[33][9] = {}, max_A[33][9] = {};
     uint32_t max_n_quiet = 0;  // ... and of the channels that emit nothing this call
 };
 
@@ -417,7 +417,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             if (p.mode == psk::PLAN_FAST) {
                 if (p.n_out) {
                     r.any_emit = true;
-                    const int Hh = p.A <= 128u ? 1 : p.A <= 256u ? 2 : 4;
+                    const int Hh = psk::fast_hist_blocks(p.A);
                     r.need_SH[p.S][Hh] = true;
                     if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
                     if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
@@ -479,7 +479,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // reference-order kernel (below) the calls both refused
     for (int exact = 0; exact <= 1; exact++)
         for (int S : kFastS)
-            for (int H = exact ? 2 : 1; H <= 4; H++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
+            for (int H = exact ? 2 : 1; H <= 8; H <<= 1)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
                 if (need_SH[S][H]) {
                     const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
                     const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;

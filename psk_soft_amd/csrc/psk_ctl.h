@@ -73,15 +73,17 @@ struct Limits {
     bool force_seq;
 };
 
-// instantiations of the wave-scan kernel: samplesPerBaud 2 .. 16 with numAvg <= 512 (window history of
-// ceil(numAvg/128) <= 4 blocks in registers), samplesPerBaud 17 .. 32 with numAvg <= 256
-constexpr uint32_t kFastMaxNumAvg = 512;
+// instantiations of the wave-scan kernel (window history of 1, 2, 4 or 8 blocks of 128 symbols in
+// registers): samplesPerBaud 2 .. 10 with numAvg <= 1024, 11 .. 16 with numAvg <= 512, 17 .. 32 with
+// numAvg <= 256
 inline bool fast_kernel_has(uint32_t S, uint32_t A)
 {
-    if (S >= 2 && S <= 16)
-        return A <= kFastMaxNumAvg;
-    return S <= 32 && A <= 256u;
+    if (S < 2 || S > 32)
+        return false;
+    return A <= (S <= 10 ? 1024u : S <= 16 ? 512u : 256u);
 }
+// history blocks of the instantiation that takes a window of numAvg symbols
+inline int fast_hist_blocks(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : A <= 512u ? 4 : 8; }
 
 // LinearFit::reset(numPts, sampleRate, forceHistoryClear) on the control state,
 // cpp/psk_soft.cpp:89-124.  Returns true (the sums must be rebuilt).

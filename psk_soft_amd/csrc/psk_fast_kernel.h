@@ -8,7 +8,7 @@
 namespace psk {
 
 // number of 128-symbol blocks of window history an instantiation keeps in registers for numAvg = A
-PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 4; }
+PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : A <= 512u ? 4 : 8; }
 
 // SV = samplesPerBaud this instantiation handles, HV = blocks of window history kept in
 // registers (numAvg <= 128 HV), EXACT = timing by the exact double pass (else the float

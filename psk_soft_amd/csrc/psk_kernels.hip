@@ -330,6 +330,15 @@ PSK_DECL_S(13)
 PSK_DECL_S(14)
 PSK_DECL_S(15)
 PSK_DECL_S(16)
+PSK_DECL_SH(2, 8)
+PSK_DECL_SH(3, 8)
+PSK_DECL_SH(4, 8)
+PSK_DECL_SH(5, 8)
+PSK_DECL_SH(6, 8)
+PSK_DECL_SH(7, 8)
+PSK_DECL_SH(8, 8)
+PSK_DECL_SH(9, 8)
+PSK_DECL_SH(10, 8)
 #define PSK_DECL_S_WIDE(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2)
 PSK_DECL_S_WIDE(17)
 PSK_DECL_S_WIDE(18)
@@ -378,6 +387,15 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     PSK_CASE_S(14)
     PSK_CASE_S(15)
     PSK_CASE_S(16)
+    PSK_CASE(2, 8)
+    PSK_CASE(3, 8)
+    PSK_CASE(4, 8)
+    PSK_CASE(5, 8)
+    PSK_CASE(6, 8)
+    PSK_CASE(7, 8)
+    PSK_CASE(8, 8)
+    PSK_CASE(9, 8)
+    PSK_CASE(10, 8)
 #define PSK_CASE_S_WIDE(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2)
     PSK_CASE_S_WIDE(17)
     PSK_CASE_S_WIDE(18)

@@ -270,9 +270,10 @@ def test_host_sized_energy_ring(oracle_mod):
 
 def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     """One instantiation of the wave-scan kernel per samplesPerBaud 2 .. 16 and window class (numAvg
-    <= 128 / <= 256 / <= 512), and for samplesPerBaud 17 .. 32 with numAvg <= 256: every one of them
-    against the oracle, ragged packets, shaped and rectangular pulses; samplesPerBaud 33 and 40, and the
-    wide symbols with numAvg 400, take the reference-order kernel."""
+    <= 128 / <= 256 / <= 512; <= 1024 up to samplesPerBaud 10), and for samplesPerBaud 17 .. 32 with
+    numAvg <= 256: every one of them against the oracle, ragged packets, shaped and rectangular pulses;
+    samplesPerBaud 33 and 40, the wide symbols with numAvg 400 and samplesPerBaud 11 .. 16 with numAvg 800
+    take the reference-order kernel."""
     import random as _random
 
     from psk_soft_amd.stimulus import gen_psk, synth_channel
@@ -280,7 +281,7 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     rng = random.Random(31)
     props, iqs, cuts = [], [], []
     for S in list(range(2, 34)) + [40]:
-        for A in (100, 200, 400):
+        for A in (100, 200, 400) + ((800,) if S <= 16 else ()):
             M = rng.choice([2, 4, 8])
             props.append(dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=rng.choice([10, 50, 200]),
                               differentialDecoding=int(rng.random() < 0.2)))
@@ -293,7 +294,7 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
             iqs.append(iq)
             cuts.append([0] + sorted(rng.sample(range(1, iq.size // 2), 2)) + [iq.size // 2])
     n_ch = len(props)
-    h = _handle(n_ch, max_window_samples=40 * 400 + 64)
+    h = _handle(n_ch, max_window_samples=16 * 1024 + 64)
     h.configure(0, props)
     got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
     for k in range(3):
@@ -303,7 +304,8 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
             for key in got[c]:
                 got[c][key].append(res[c][key])
     st = h.stats()
-    assert st["channels_sequential"] - st["channels_guard"] == 6 + 16, st  # samplesPerBaud 33 and 40 (three windows each), 17 .. 32 at numAvg 400
+    # samplesPerBaud 33 and 40 (three windows each), 17 .. 32 at numAvg 400, 11 .. 16 at numAvg 800
+    assert st["channels_sequential"] - st["channels_guard"] == 6 + 16 + 6, st
     for c in range(n_ch):
         o = oracle_mod.OracleComponent()
         for kk, v in props[c].items():

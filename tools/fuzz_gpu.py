@@ -76,7 +76,7 @@ def main():
         props, sigs, scripts = [], [], []
         for c in range(C):
             S = rng.choice([2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 33] + list(range(17, 33)))
-            A = rng.choice([1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520])
+            A = rng.choice([1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520, 513, 1024])
             M = rng.choice([2, 4, 4, 8])
             n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400, 900, 1920, 1921])
             p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
@@ -98,7 +98,7 @@ def main():
             props.append(p)
             sigs.append(sig)
             scripts.append(ev)
-        h = pl.Handle(C, device=0, max_window_samples=33 * 520 + 64, max_phase_avg=2048)
+        h = pl.Handle(C, device=0, max_window_samples=33 * 1024 + 64, max_phase_avg=2048)
         h.configure(0, props)
         oracles = []
         for c in range(C):
