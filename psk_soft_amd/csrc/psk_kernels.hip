@@ -339,7 +339,13 @@ PSK_DECL_SH(7, 8)
 PSK_DECL_SH(8, 8)
 PSK_DECL_SH(9, 8)
 PSK_DECL_SH(10, 8)
-#define PSK_DECL_S_WIDE(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2)
+PSK_DECL_SH(11, 8)
+PSK_DECL_SH(12, 8)
+PSK_DECL_SH(13, 8)
+PSK_DECL_SH(14, 8)
+PSK_DECL_SH(15, 8)
+PSK_DECL_SH(16, 8)
+#define PSK_DECL_S_WIDE(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S_WIDE(17)
 PSK_DECL_S_WIDE(18)
 PSK_DECL_S_WIDE(19)
@@ -396,7 +402,13 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     PSK_CASE(8, 8)
     PSK_CASE(9, 8)
     PSK_CASE(10, 8)
-#define PSK_CASE_S_WIDE(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2)
+    PSK_CASE(11, 8)
+    PSK_CASE(12, 8)
+    PSK_CASE(13, 8)
+    PSK_CASE(14, 8)
+    PSK_CASE(15, 8)
+    PSK_CASE(16, 8)
+#define PSK_CASE_S_WIDE(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S_WIDE(17)
     PSK_CASE_S_WIDE(18)
     PSK_CASE_S_WIDE(19)
