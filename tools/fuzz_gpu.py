@@ -18,6 +18,11 @@ from psk_soft_amd import lib as pl  # noqa: E402
 
 TOL = 1e-5
 XD = 0.01
+# PSK_FUZZ_S / PSK_FUZZ_A: comma-separated lists that replace the default draws (to aim a run at some instantiations)
+S_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_S"].split(",")] if os.environ.get("PSK_FUZZ_S") else (
+    [2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 33] + list(range(17, 33)))
+A_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_A"].split(",")] if os.environ.get("PSK_FUZZ_A") else (
+    [1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520, 513, 1024])
 
 
 def make_signal(rng, nrng, M, S, n):
@@ -75,8 +80,8 @@ def main():
         nrng = np.random.default_rng(seed * 1000 + rnd)
         props, sigs, scripts = [], [], []
         for c in range(C):
-            S = rng.choice([2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 33] + list(range(17, 33)))
-            A = rng.choice([1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520, 513, 1024])
+            S = rng.choice(S_CHOICES)
+            A = rng.choice(A_CHOICES)
             M = rng.choice([2, 4, 4, 8])
             n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400, 900, 1920, 1921])
             p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
