@@ -727,8 +727,13 @@ psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats
     if (!h || !stats)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "null argument");
     std::memset(stats, 0, sizeof *stats);
-    if (h->dry)
+    if (h->dry) {  // control plane only: which kernel the last call was PLANNED for, per channel
+        for (uint32_t c = 0; c < h->nch; c++) {
+            if (h->last_mode[c] == psk::PLAN_FAST) stats->channels_fast++;
+            if (h->last_mode[c] == psk::PLAN_SEQ || h->last_mode[c] == psk::PLAN_SEQ_S1) stats->channels_sequential++;
+        }
         return PSK_SOFT_OK;
+    }
     psk_soft_status st = psk_soft_synchronize(h);
     if (st != PSK_SOFT_OK)
         return st;
