@@ -109,7 +109,8 @@ typedef struct psk_soft_output {
 
 typedef struct psk_soft_handle psk_soft_handle_t;
 
-/* Runtime statistics of the last psk_soft_process_* call (read after psk_soft_synchronize). */
+/* Runtime statistics of the last psk_soft_process_* call (read after psk_soft_synchronize).  A control-
+ * plane-only handle (PSK_SOFT_DEVICE_NONE) fills in channels_fast / channels_sequential as PLANNED. */
 typedef struct psk_soft_stats {
     uint64_t channels_fast;       /* channels handled by a wave-scan kernel                        */
     uint64_t channels_exact_timing; /* of those: calls whose timing screening refused (near-ties) and
