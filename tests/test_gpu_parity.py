@@ -355,6 +355,35 @@ def test_long_phase_averages_stay_on_the_wave_scan_kernel(oracle_mod):
     h.close()
 
 
+def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod):
+    """A case the randomised comparison found (tools/fuzz_gpu.py seed 1002, round 5, channel 194; the
+    signal is tests/golden/cases/s11_a257_tail.npy, made by that tool's generator): samplesPerBaud 11,
+    numAvg 257, near-ties that send both calls through the exact-timing instantiation <11, 4, true>
+    (304 VGPRs), the second call ending in a partial block of 84 symbols.  An experimental build (a loop
+    added to fit_block that was never executed) wrote garbage soft symbols for exactly those 84; the
+    committed code is right, and this keeps it so."""
+    import os
+
+    sig = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases", "s11_a257_tail.npy"))
+    props = dict(samplesPerBaud=11, constelationSize=4, numAvg=257, phaseAvg=385, differentialDecoding=0)
+    cuts = [0, 35342, 132000]
+    h = _handle(1, max_window_samples=11 * 257 + 64, max_phase_avg=512)
+    h.configure(0, [props])
+    o = oracle_mod.OracleComponent()
+    for k, v in props.items():
+        setattr(o, k, v)
+    for k in range(2):
+        d = sig[2 * cuts[k] : 2 * cuts[k + 1]]
+        g = h.process_host(0, [dict(data=d, xdelta=0.01, sriChanged=(k == 0))])[0]
+        st = h.stats()
+        assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
+        r = o.service(d, 0.01, sriChanged=(k == 0))
+        assert r.phase.size % 128 != 0
+        assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "call %d" % k)
+        assert np.array_equal(g["soft"].view(np.uint32), r.soft.view(np.uint32)), "call %d: soft not bit-identical" % k
+    h.close()
+
+
 def test_random_configuration_sweep(oracle_mod):
     """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
     and ragged packetisation, three calls each, every stream against the oracle: a broad net for

@@ -103,6 +103,9 @@ def main():
             props.append(p)
             sigs.append(sig)
             scripts.append(ev)
+            if os.environ.get("PSK_FUZZ_DUMP") and int(os.environ["PSK_FUZZ_DUMP"]) == c:  # with a single-round replay: keep this channel's case
+                np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_case_sig.npy"), sig)
+                print("DUMPED channel %d: props=%s script=%s" % (c, p, ev))
         h = pl.Handle(C, device=0, max_window_samples=33 * 1024 + 64, max_phase_avg=2048)
         h.configure(0, props)
         oracles = []
@@ -171,6 +174,10 @@ def main():
                                  dp[0], g["phase"][dp[0]], r["phase"][dp[0]],
                                  abs(int(g["phase"][dp[0]:dp[0] + 1].view(np.int32)[0]) - int(r["phase"][dp[0]:dp[0] + 1].view(np.int32)[0]))),
                              ds.size, float(np.abs(r["phase"][np.isfinite(r["phase"])]).max())))
+                    if ds.size:
+                        sym = np.unique(ds // 2)
+                        print("   soft differs at symbols %s ... (%d symbols); got %s ref %s" % (
+                            sym[:16].tolist(), sym.size, g["soft"][2 * sym[0] : 2 * sym[0] + 2], r["soft"][2 * sym[0] : 2 * sym[0] + 2]))
         bad_total += bad
         print("round %d: %d channels, %d mismatches, last-call stats %s" % (rnd, C, bad, st))
     print("TOTAL mismatches:", bad_total)
