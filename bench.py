@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall seconds of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="verify a few channels against the oracle after the run")
+    ap.add_argument("--chain-hist", action="store_true", help="per-channel histogram of fit_chain_blocks of the last step (to stderr)")
     return ap.parse_args()
 
 
@@ -228,6 +229,13 @@ def main():
     probe_ms = h.probe_read_ms(iq.data_ptr(), iq.numel() * 4, reps=5)
     st = h.stats()
     n_out = int(out[0].n_symbols)
+    if a.chain_hist and rank == 0:
+        import collections
+
+        cs = [c["fit_chain_blocks"] for c in h.channel_stats()]
+        hist = collections.Counter(min(v // 16, 16) for v in cs)
+        sys.stderr.write("chain blocks per channel (bins of 16): %s; max %d; channels over 128: %s\n"
+                         % (sorted(hist.items()), max(cs), [i for i, v in enumerate(cs) if v > 128][:20]))
 
     samples_per_step = C * N * world
     value = samples_per_step * a.steps / elapsed / 1e6

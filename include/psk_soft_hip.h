@@ -121,6 +121,9 @@ typedef struct psk_soft_stats {
     uint64_t unwrap_blocks;       /* 128-symbol blocks processed by the wave-scan kernel           */
     uint64_t timing_exact_blocks; /* of those: blocks whose timing argmax needed the exact double pass
                                      (in the screened kernel, numAvg <= 128, or in the exact kernel) */
+    uint64_t fit_chain_blocks;    /* of those: blocks whose LinearFit sums were redone in the reference's
+                                     order of additions by the lane-after-lane chain (the wave-parallel
+                                     candidates did not verify: sums crossing a binade or zero)          */
 } psk_soft_stats_t;
 
 uint32_t psk_soft_abi_version(void);
@@ -159,6 +162,8 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
                                       const psk_soft_packet_t *pkts, psk_soft_output_t *outs);
 psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h);
 psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats);
+/* the same, one record per channel of [ch0, ch0+nch) (stats[nch]) */
+psk_soft_status psk_soft_get_channel_stats(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, psk_soft_stats_t *stats);
 
 /* Options of a handle (all default 0 = the reference's behaviour, quirks included).
  * PSK_SOFT_OPT_QPSK_SIGN_BITMAP: 1 = QPSK bits by the signs of the de-rotated symbol, as the

@@ -722,44 +722,59 @@ psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h)
     return PSK_SOFT_OK;
 }
 
-psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats)
+static void stats_add(psk_soft_stats_t *stats, uint32_t mode, const psk::ChanState &s)
 {
-    if (!h || !stats)
-        return fail(PSK_SOFT_ERR_INVALID_ARG, "null argument");
-    std::memset(stats, 0, sizeof *stats);
+    switch (mode) {
+    case psk::PLAN_FAST:
+        if (s.guard == 2u) {
+            stats->channels_sequential++;
+            stats->channels_guard++;
+        } else {
+            stats->channels_fast++;
+            if (s.guard == 3u)
+                stats->channels_exact_timing++;
+            stats->unwrap_blocks += s.stat_blocks;
+            stats->unwrap_extra_passes += s.stat_extra;
+            stats->timing_exact_blocks += s.stat_exact;
+            stats->fit_chain_blocks += s.stat_chain;
+        }
+        break;
+    case psk::PLAN_SEQ:
+    case psk::PLAN_SEQ_S1: stats->channels_sequential++; break;
+    default: break;
+    }
+}
+
+static psk_soft_status stats_range(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, psk_soft_stats_t *stats, bool per_channel)
+{
+    if (!h || !stats || (uint64_t)ch0 + nch > h->nch)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_get_stats: bad arguments");
+    std::memset(stats, 0, sizeof *stats * (per_channel ? nch : 1));
     if (h->dry) {  // control plane only: which kernel the last call was PLANNED for, per channel
-        for (uint32_t c = 0; c < h->nch; c++) {
-            if (h->last_mode[c] == psk::PLAN_FAST) stats->channels_fast++;
-            if (h->last_mode[c] == psk::PLAN_SEQ || h->last_mode[c] == psk::PLAN_SEQ_S1) stats->channels_sequential++;
+        for (uint32_t c = 0; c < nch; c++) {
+            psk_soft_stats_t *o = per_channel ? stats + c : stats;
+            if (h->last_mode[ch0 + c] == psk::PLAN_FAST) o->channels_fast++;
+            if (h->last_mode[ch0 + c] == psk::PLAN_SEQ || h->last_mode[ch0 + c] == psk::PLAN_SEQ_S1) o->channels_sequential++;
         }
         return PSK_SOFT_OK;
     }
     psk_soft_status st = psk_soft_synchronize(h);
     if (st != PSK_SOFT_OK)
         return st;
-    std::vector<psk::ChanState> s(h->nch);
-    PSK_HIP(hipMemcpy(s.data(), h->d_state, sizeof(psk::ChanState) * h->nch, hipMemcpyDeviceToHost));
-    for (uint32_t c = 0; c < h->nch; c++) {
-        switch (h->last_mode[c]) {
-        case psk::PLAN_FAST:
-            if (s[c].guard == 2u) {
-                stats->channels_sequential++;
-                stats->channels_guard++;
-            } else {
-                stats->channels_fast++;
-                if (s[c].guard == 3u)
-                    stats->channels_exact_timing++;
-                stats->unwrap_blocks += s[c].stat_blocks;
-                stats->unwrap_extra_passes += s[c].stat_extra;
-                stats->timing_exact_blocks += s[c].stat_exact;
-            }
-            break;
-        case psk::PLAN_SEQ:
-        case psk::PLAN_SEQ_S1: stats->channels_sequential++; break;
-        default: break;
-        }
-    }
+    std::vector<psk::ChanState> s(nch);
+    PSK_HIP(hipMemcpy(s.data(), h->d_state + ch0, sizeof(psk::ChanState) * nch, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < nch; c++) stats_add(per_channel ? stats + c : stats, h->last_mode[ch0 + c], s[c]);
     return PSK_SOFT_OK;
+}
+
+psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats)
+{
+    return stats_range(h, 0, h ? h->nch : 0, stats, false);
+}
+
+psk_soft_status psk_soft_get_channel_stats(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, psk_soft_stats_t *stats)
+{
+    return stats_range(h, ch0, nch, stats, true);
 }
 
 psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)

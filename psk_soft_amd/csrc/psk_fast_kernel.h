@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
     cy.stat_blocks = 0;
     cy.stat_extra = 0;
     cy.stat_exact_blocks = 0;
+    cy.stat_chain = 0;
+    cy.chain_run = 0;
+    cy.chain_streak = 0;
     if (p.lf_flags & LF_RECOMPUTE) {
         fit_rebuild_sums([&](uint32_t j) { return yring[j & ymask]; }, len0, p.lf_xdelta, cy.ySum, cy.xySum);
         fit_denominator(p.lf_xdelta, len0, cy.den, cy.xavg);
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
             st->stat_blocks = cy.stat_blocks;
             st->stat_extra = cy.stat_extra;
             st->stat_exact = cy.stat_exact_blocks;
+            st->stat_chain = cy.stat_chain;
         }
     }
 }

@@ -58,6 +58,9 @@ struct FastCarry {
                            // exactness guard decide whether the call may stay here
     bool refuse;
     uint32_t stat_blocks, stat_extra, stat_exact_blocks;
+    uint32_t stat_chain;   // blocks whose LinearFit sums went through the reference-order chain (fit_sums_chain)
+    uint32_t chain_run;    // > 0: the chain ran on two blocks in a row -- the next blocks go straight to it (see fast_main_loop)
+    uint32_t chain_streak;
 };
 
 // exactness guard bookkeeping: max of the energy bit patterns and min of (bits - 1); a zero
@@ -292,14 +295,14 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
 // repeats until nothing changes.  This is a guess: everything is verified by the exact pass that
 // follows, an overflow of the packed sums or a float near-tie only costs another pass.
 constexpr int kRefineMax = 12;
-PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&est)[kR], const double (&rawd)[kR],
+PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&est)[kR], const float (&raw)[kR],
                            const bool (&valid)[kR], const int (&w_base)[kR], int (&w2)[kR])
 {
     const float inv2pi = 0.15915494f;
     const float nn = (float)n * (float)(n + 1u);
     const float alpha = 6.2831853f * (float)(4u * n - 2u) / nn, beta = 6.2831853f * 6.0f / nn;
     const int s0 = 2 * lane, s1 = s0 + 1;
-    const float raw0 = (float)rawd[0], raw1 = (float)rawd[1];
+    const float raw0 = raw[0], raw1 = raw[1];
     const float qb0 = __builtin_rintf((est_prev0 - raw0) * inv2pi), qb1 = __builtin_rintf((est[0] - raw1) * inv2pi);
     int d0 = valid[0] ? w2[0] - w_base[0] : 0, d1 = valid[1] ? w2[1] - w_base[1] : 0;
     // where position s - n lives (n < 128; otherwise the window reaches back past the block start)
@@ -338,6 +341,172 @@ PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&
     w2[1] = w_base[1] + d1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LinearFit::next's running sums in the REFERENCE'S ORDER of additions (cpp/psk_soft.cpp:70-79):
+//     ySum -= front;  xySum -= xdelta*ySum;  ySum += y;  xySum += y*size*xdelta      per symbol.
+// xdelta*ySum is a rounded double product, so xySum depends on the order of its additions at the
+// 2^-53 level, and through the float roundings of calculateFit that reaches the outputs (a one-ulp
+// flip of phaseEstimate now and then: 6e-5 rad once the estimate has grown past 512 rad).  The sums of a
+// block are therefore produced so that they ARE the sequential ones, in three steps:
+//   1. candidates, wave-parallel: ySum by a prefix scan (exact whenever the reference's own additions are:
+//      float addends of similar size); xySum by xysum_grid below;
+//   2. fit_sums_verify: every position re-runs the reference's statements on its predecessor's sums and
+//      compares bits.  If all positions agree the candidates are the sequential sums, by induction from the
+//      carried sums -- whatever produced them; nothing else is trusted;
+//   3. otherwise fit_sums_chain runs the recurrence itself, lane after lane.
+// ---------------------------------------------------------------------------------------------
+PSK_DEV double pow2_biased(int eb) { return __hiloint2double((int)((unsigned)eb << 20), 0); }
+PSK_DEV bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+PSK_DEV bool odd_f64(double n) { return __builtin_amdgcn_fract(n * 0.5) != 0.0; }  // n integer-valued
+
+// xySum candidates for the 128 positions of a block, in the reference's order of roundings.
+//     r_j = fl(s_{j-1} - c_j),  s_j = fl(r_j + t_j);   c_j = fl(xdelta*ySum) (53 bits), t_j a float.
+// Let [2^p, 2^(p+1)) be the binade of the intermediates r_j and q = 2^(p-52) its ulp; everything is scaled
+// to units of q (exact).
+//   mode A, |s| < 2^(p+1): s_{j-1} is a multiple of q, so step j subtracts RN(c_j) whatever the state --
+//     except on an exact tie (c_j has some five bits below q: one step in 32), which goes to the even
+//     neighbour and so depends on the parity of s_{j-1}.  r_j + t_j is exact.  After a tie the parity is
+//     known (even, plus t_j), hence the parity at every position follows from a SEGMENTED xor scan, here by
+//     ballots and mbcnt; the tie corrections are added to the increments and ONE prefix sum -- exact: integers
+//     below 2^53 -- yields all s_j.  (Sums near zero, |s| << |c|, are covered too: c is then on the grid
+//     itself and nothing rounds.)
+//   mode B, 2^(p+1) <= |s| < 2^(p+2) (the sums sit just above a power of two and the intermediates dip below
+//     it, one block in 16): s_{j-1} is an EVEN multiple of q, so the first rounding is settled locally; the
+//     second one, to multiples of 2, is exact for an even r_j + t_j and a state-dependent tie for an odd one.
+// Anything else (intermediates changing binade, operands off the grid, non-finite values) produces
+// candidates that fit_sums_verify rejects.  tools/model/xysum_grid_model.cpp is the CPU model of this.
+PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const double (&t)[kR], double (&xs)[kR])
+{
+    const double r_first = s_c - read_lane(c[0], 0);          // (wave-uniform, like s_c)
+    const int eb = (__double2hiint(r_first) >> 20) & 0x7ff;   // biased exponent of the intermediates' binade
+    const double q = pow2_biased(eb - 52), inv_q = pow2_biased(2098 - eb);
+    const bool modeB = !(__builtin_fabs(s_c) < pow2_biased(eb + 1));
+    const double S_c = s_c * inv_q;
+    // Per position: T = a state-dependent tie; V = parity of s_j (mode B: of s_j / 2), absolute after a tie,
+    // else relative to s_{j-1}; E (mode B) = which neighbour an even s_{j-1}/2 selects; inc = s_j - s_{j-1}
+    // before the tie correction.  RN(c) = rint(c) is EVEN at a tie, so s_{j-1} - RN(c) has the parity of s_{j-1}:
+    // mode A picks the neighbour by that parity alone, and mode B's first rounding never needs a correction.
+    bool T[kR], V[kR], E[kR], dpos[kR];
+    double inc[kR];
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        const double nc = c[r] * inv_q, nt = t[r] * inv_q;
+        const double ch = __builtin_rint(nc);  // RN(c), ties to even
+        inc[r] = nt - ch;
+        if (!modeB) {
+            const double d = nc - ch;
+            T[r] = __builtin_fabs(d) == 0.5;
+            dpos[r] = d > 0.0;  // the tie lies below RN(c): the other neighbour is one step down
+            E[r] = false;
+            V[r] = odd_f64(inc[r]);  // after a tie: even + t, and inc = t - even
+        } else {
+            T[r] = odd_f64(inc[r]);  // r_j + t_j odd: the rounding to multiples of 2 is a tie
+            const bool hw = odd_f64((T[r] ? inc[r] - 1.0 : inc[r]) * 0.5);
+            E[r] = hw;
+            V[r] = !T[r] && hw;
+            dpos[r] = false;
+        }
+    }
+    // parity entering this lane: the lane's two positions composed, then segmented over the wave
+    const bool Ac = T[0] || T[1];
+    const bool Vc = T[1] ? V[1] : (V[0] != V[1]);
+    const unsigned long long mA = __ballot(Ac), mV = __ballot(Vc);
+    const bool G = (__builtin_amdgcn_mbcnt_hi((unsigned)(mV >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mV, 0u)) & 1u) != 0;
+    const unsigned long long mF = __ballot(Ac && G);
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const unsigned long long X = mA & lt, Y = mF & lt;  // ties below this lane; ... those whose G is odd
+    const bool P_c = modeB ? odd_f64(S_c * 0.5) : odd_f64(S_c);
+    const bool P_in = (X ? (Y > (X >> 1)) : P_c) != G;  // G at the last tie below this lane, else the carry's parity
+    const bool sel0 = P_in != E[0];
+    const bool P0 = T[0] ? V[0] : (P_in != V[0]);
+    const bool sel1 = P0 != E[1];
+    double a0, a1;
+    if (!modeB) {
+        a0 = inc[0] + ((T[0] && sel0) ? (dpos[0] ? -1.0 : 1.0) : 0.0);
+        a1 = inc[1] + ((T[1] && sel1) ? (dpos[1] ? -1.0 : 1.0) : 0.0);
+    } else {
+        a0 = inc[0] + (T[0] ? (sel0 ? 1.0 : -1.0) : 0.0);
+        a1 = inc[1] + (T[1] ? (sel1 ? 1.0 : -1.0) : 0.0);
+    }
+    const double incl = wave_scan_f64(a0 + a1);
+    const double x0 = (S_c + wave_up1(incl, 0.0)) + a0;
+    xs[0] = x0 * q;
+    xs[1] = (x0 + a1) * q;
+}
+
+// Do the candidate sums of a block equal the reference's sequential ones?  Every valid position
+// re-runs cpp/psk_soft.cpp:70-79 on its predecessor's sums and compares bits (z = 0 where the window is
+// still filling: the reference skips the pop there, and x - 0 is x).  bit 0: ySum fails, bit 1: xySum fails
+// (a NaN never verifies: its bits differ from case to case; the chain then produces the reference's own).
+PSK_DEV int fit_sums_verify(const bool (&valid)[kR], double ySum_c, double xySum_c, const float (&z)[kR], const float (&y)[kR],
+                            const double (&ySumP)[kR], const double (&c)[kR], const double (&t)[kR],
+                            const double (&ySum_l)[kR], const double (&xySum_l)[kR])
+{
+    // (ySumP[1] is ySum_l[0] - z[1] by construction; ySumP[0] came from the scanned base, which must be the
+    // predecessor's candidate sum)
+    const double ys_prev = wave_up1(ySum_l[1], ySum_c), xs_prev = wave_up1(xySum_l[1], xySum_c);
+    const bool y0 = same_bits(ys_prev - (double)z[0], ySumP[0]) && same_bits(ySumP[0] + (double)y[0], ySum_l[0]);
+    const bool y1 = same_bits(ySumP[1] + (double)y[1], ySum_l[1]);
+    const bool x0 = same_bits((xs_prev - c[0]) + t[0], xySum_l[0]);
+    const bool x1 = same_bits((xySum_l[0] - c[1]) + t[1], xySum_l[1]);
+    const bool y_ok = __all((y0 || !valid[0]) && (y1 || !valid[1]));
+    const bool x_ok = __all((x0 || !valid[0]) && (x1 || !valid[1]));
+    return (y_ok ? 0 : 1) | (x_ok ? 0 : 2);
+}
+
+// The recurrence itself (cpp/psk_soft.cpp:70-79), lane after lane: in step k every lane takes the sums
+// its left neighbour holds and runs its own two symbols; lane k's neighbour is final from step k - 1 on, so
+// after lane_last + 1 steps every valid position holds the reference's sums (a lane that is already final
+// recomputes the same values).  with_y = false: ySum_l holds verified sums, only xySum is chained.  The two sums
+// are chained one after the other (ySum does not depend on xySum): two short loops of 2 moves + 4 dependent
+// additions a step instead of one long one.
+template <bool WARM>
+PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, uint32_t n, float xd, float sizef_steady,
+                            double ySum_c, double xySum_c, const bool (&valid)[kR], const float *yring, uint32_t ymask,
+                            const float (&y)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR])
+{
+    const double xdd = (double)xd;
+    // operands rebuilt from what the block left behind (the ring holds every y of the window; positions past
+    // the end, and pops where the window is still filling, get zero operands: x - 0 and x + 0 are x, so the
+    // loops need no selects)
+    double zz[kR], yy[kR], tt[kR];
+    bool steady[kR];
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        const uint32_t before = q0 + (uint32_t)(2 * lane + r);
+        steady[r] = WARM ? before >= n : true;
+        const float sizef = WARM ? (float)(steady[r] ? n - 1 : before) : sizef_steady;
+        const float zf = yring[(before - n) & ymask];
+        zz[r] = (valid[r] && steady[r]) ? (double)zf : 0.0;
+        yy[r] = valid[r] ? (double)y[r] : 0.0;
+        float tf = y[r] * sizef;  // :78, size before the push
+        tf = tf * xd;
+        tt[r] = valid[r] ? (double)tf : 0.0;
+    }
+    if (with_y) {
+        double ys = ySum_c;
+#pragma unroll 1
+        for (int k = 0; k <= lane_last; k++) {
+            const double a = wave_up1(ys, ySum_c);
+            ySum_l[0] = (a - zz[0]) + yy[0];  // ySum -= yvals.front(), :70;  ySum += yval, :77
+            ySum_l[1] = (ySum_l[0] - zz[1]) + yy[1];
+            ys = ySum_l[1];
+        }
+    }
+    // xdelta*ySum after each pop, :72 (ySum_l holds the reference's sums by now)
+    const double ys_prev = wave_up1(ySum_l[1], ySum_c);
+    const double c0 = (valid[0] && steady[0]) ? xdd * (ys_prev - zz[0]) : 0.0;
+    const double c1 = (valid[1] && steady[1]) ? xdd * (ySum_l[0] - zz[1]) : 0.0;
+    double xs = xySum_c;
+#pragma unroll 1
+    for (int k = 0; k <= lane_last; k++) {
+        const double b = wave_up1(xs, xySum_c);
+        xySum_l[0] = (b - c0) + tt[0];  // :72 and :78
+        xySum_l[1] = (xySum_l[0] - c1) + tt[1];
+        xs = xySum_l[1];
+    }
+}
+
 // One block (128 symbols) of the feedback unwrap + LinearFit::next recurrence
 // (reference cpp/psk_soft.cpp:477-482, 48-87, 135-174).  The recurrence
 //     est[i-1] -> numWraps[i] -> y[i] -> (ySum, xySum) -> est[i]
@@ -350,9 +519,9 @@ PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&
 // the block's last valid symbol.
 template <bool WARM>
 PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk,
-                      const bool (&valid)[kR], const double (&rawd)[kR], const FastCarry &cy,
+                      const bool (&valid)[kR], const float (&raw)[kR], const FastCarry &cy,
                       float *yring, uint32_t ymask, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
-                      int lane_last, int r_last, float &den_last, float &xavg_last)
+                      int lane_last, int r_last, float &den_last, float &xavg_last, bool cheap, int &rejected)
 {
     uint32_t before[kR];
     bool steady[kR];
@@ -390,20 +559,18 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             const float pred = cy.est + cy.slope * (float)(2 * lane + r);
-            w[r] = (int)__builtin_rintf((pred - (float)rawd[r]) * inv2pi);
+            w[r] = (int)__builtin_rintf((pred - raw[r]) * inv2pi);
         }
     }
     const double two_pi = PSK_KD(kTwoPi, (int)q0);
     int pass = 0;
     for (;;) {
-        double y_d[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
-            double yd = rawd[r] + (double)(long long)w[r] * two_pi;  // cpp/psk_soft.cpp:478
+            double yd = (double)raw[r] + (double)(long long)w[r] * two_pi;  // cpp/psk_soft.cpp:478 (thisPhase is a float widened, :474)
             y[r] = (float)yd;                                         // next(float yval), :481
             if (valid[r])
                 yring[before[r] & ymask] = y[r];
-            y_d[r] = (double)y[r];  // (positions past the end only feed sums past the end)
         }
         wave_lds_fence();
         float z[kR];
@@ -411,23 +578,34 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         for (int r = 0; r < kR; r++)
             z[r] = steady[r] ? yring[(before[r] - n) & ymask] : 0.0f;  // yvals.front(), :70
         wave_lds_fence();
-        const double dy0 = y_d[0] - (double)z[0], dy1 = y_d[1] - (double)z[1];
-        double incl = wave_scan_f64(dy0 + dy1);
-        double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
-        double ySumP0 = base - (double)z[0];           // ySum after the pop, :70
-        ySum_l[0] = base + dy0;
-        double ySumP1 = ySum_l[0] - (double)z[1];
-        ySum_l[1] = ySum_l[0] + dy1;
-        float t0 = y[0] * sizef[0];                    // :78, size before the push
+        float t0 = y[0] * sizef[0];  // :78, size before the push
         t0 = t0 * xd;
         float t1 = y[1] * sizef[1];
         t1 = t1 * xd;
-        double c0 = (double)t0 - (steady[0] ? (double)xd * ySumP0 : 0.0);  // :72 and :78
-        double c1 = (double)t1 - (steady[1] ? (double)xd * ySumP1 : 0.0);
-        double incl2 = wave_scan_f64(c0 + c1);
-        double base2 = cy.xySum + wave_up1(incl2, 0.0);
-        xySum_l[0] = base2 + c0;
-        xySum_l[1] = xySum_l[0] + c1;
+        const double t_d[kR] = {valid[0] ? (double)t0 : 0.0, valid[1] ? (double)t1 : 0.0};
+        // candidate sums, wave-parallel (see xysum_grid), verified on the spot
+        const double dy0 = valid[0] ? (double)y[0] - (double)z[0] : 0.0, dy1 = valid[1] ? (double)y[1] - (double)z[1] : 0.0;
+        const double incl = wave_scan_f64(dy0 + dy1);
+        const double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
+        ySum_l[0] = base + dy0;
+        ySum_l[1] = ySum_l[0] + dy1;
+        double ySumP[kR], c_d[kR];
+        ySumP[0] = base - (double)z[0];  // ySum after the pop, :70
+        ySumP[1] = ySum_l[0] - (double)z[1];
+        c_d[0] = (valid[0] && steady[0]) ? (double)xd * ySumP[0] : 0.0;  // :72
+        c_d[1] = (valid[1] && steady[1]) ? (double)xd * ySumP[1] : 0.0;
+        if (WARM || cheap) {
+            // (the caller runs the recurrence for xySum over this block anyway: any guess will do here)
+            const double cc0 = t_d[0] - c_d[0], cc1 = t_d[1] - c_d[1];
+            const double i2 = wave_scan_f64(cc0 + cc1);
+            const double b2 = cy.xySum + wave_up1(i2, 0.0);
+            xySum_l[0] = b2 + cc0;
+            xySum_l[1] = xySum_l[0] + cc1;
+            rejected = WARM ? 3 : (2 | (fit_sums_verify(valid, cy.ySum, cy.xySum, z, y, ySumP, c_d, t_d, ySum_l, xySum_l) & 1));
+        } else {
+            xysum_grid(lane, cy.xySum, c_d, t_d, xySum_l);
+            rejected = fit_sums_verify(valid, cy.ySum, cy.xySum, z, y, ySumP, c_d, t_d, ySum_l, xySum_l);
+        }
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             float m_ = 0.0f, b_;
@@ -439,7 +617,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
                 est[r] = y[r];
             }
         }
-        float est_prev0 = wave_up1(est[1], cy.est);
+        const float est_prev0 = wave_up1(est[1], cy.est);
         {
             // round((est_prev - raw)/2pi) == w  <=>  |est_prev - (raw + 2 pi w)| < pi; with the
             // unwrapped value y within 3.0 of the feedback (and small enough that its float
@@ -450,14 +628,14 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             if (__all(sure0 && sure1))
                 break;
         }
-        int w2_0 = (int)unwrap_count(est_prev0, rawd[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
-        int w2_1 = (int)unwrap_count(est[0], rawd[1], (int)q0);
-        bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
+        int w2_0 = (int)unwrap_count(est_prev0, (double)raw[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
+        int w2_1 = (int)unwrap_count(est[0], (double)raw[1], (int)q0);
+        const bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
         if (!__any(bad))
             break;
         int w2[kR] = {w2_0, w2_1};
         if (!WARM)
-            refine_unwrap(lane, n, est_prev0, est, rawd, valid, w, w2);
+            refine_unwrap(lane, n, est_prev0, est, raw, valid, w, w2);
         w[0] = w2[0];
         w[1] = w2[1];
         if (++pass > kMaxUnwrapPasses)
@@ -803,7 +981,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 d1v[k] = cur.e[1][k] - e_old[1][k];
                 inc[k] = d0 + d1v[k];
             }
-            wave_scan_f32_multi<S>(inc);
+            wave_scan_f32_multi(inc);
             int m1[kR], m2[kR];
 #pragma unroll
             for (int k = 0; k < S; k++) {
@@ -924,15 +1102,22 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
         hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
 
-        __builtin_amdgcn_s_setprio(0);
+        // (a wave whose sums need the lane-after-lane chain -- a stationary carrier sitting at zero phase -- pays
+        // ~2 us of pure latency per block there.  The launch waits for its slowest wave, so such a wave keeps a
+        // raised priority through the arithmetic half too: its other work then runs ahead of its neighbours'
+        // and the wave keeps pace with them.  There are a handful of them in thousands.)
+        if (cy.chain_run)
+            __builtin_amdgcn_s_setprio(2);
+        else
+            __builtin_amdgcn_s_setprio(0);
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
-        double rawd[kR];
+        float raw[kR];  // arg(pow(sample, M)): a float (std::arg of complex<float>), widened where the reference widens it
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             cf32 pw = cpow_uint<false>(s[r], M);
             if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
                 cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
-            rawd[r] = (double)atan2f_wave(pw.im, pw.re, atab);
+            raw[r] = atan2f_wave(pw.im, pw.re, atab);
         }
 
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
@@ -940,13 +1125,61 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         float y[kR], est[kR];
         double ySum_l[kR], xySum_l[kR];
         float den_last = den_s, xavg_last = xavg_s;
-        int pass;
-        if (__builtin_expect(q0 >= n, 1)) {
-            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                                    lane_last, r_last, den_last, xavg_last);
-        } else {  // the fit window is still filling: the first phaseAvg symbols after a history clear
-            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, rawd, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                                   lane_last, r_last, den_last, xavg_last);
+        int pass, rejected = 0;
+        const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
+        const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
+        if (!warm) {
+            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+                                    lane_last, r_last, den_last, xavg_last, cheap, rejected);
+        } else {
+            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+                                   lane_last, r_last, den_last, xavg_last, cheap, rejected);
+        }
+        if (rejected) {
+            // The candidates are not the reference's sums (or were not attempted): the recurrence itself, then the
+            // estimates from ITS sums.  The unwrap counts were verified against the candidates' estimates, which
+            // differ from these by an ulp here and there: a count that would change under them (a feedback within
+            // an ulp of the half-way point of the unwrap) sends the call to the reference-order kernel.
+            if (!warm)
+                fit_sums_chain<false>((rejected & 1) != 0, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
+            else
+                fit_sums_chain<true>(true, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
+            float est2[kR];
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                float m_, b_;
+                if (!warm) {
+                    est2[r] = fit_value_known(ySum_l[r], xySum_l[r], fk, m_);
+                } else {
+                    const uint32_t before = q0 + (uint32_t)(2 * lane + r);
+                    const uint32_t pts = before < n ? before + 1 : n;
+                    float den_r = den_s, xavg_r = xavg_s;
+                    if (pts > 1 && pts < n)
+                        fit_denominator(xd, pts, den_r, xavg_r);
+                    est2[r] = pts > 1 ? fit_value(ySum_l[r], xySum_l[r], xd, pts, den_r, xavg_r, m_, b_) : y[r];
+                }
+            }
+            const float fb0 = wave_up1(est2[1], cy.est), old_fb0 = wave_up1(est[1], cy.est);
+            const bool diff0 = valid[0] && __float_as_uint(fb0) != __float_as_uint(old_fb0);
+            const bool diff1 = valid[1] && __float_as_uint(est2[0]) != __float_as_uint(est[0]);
+            if (__any(diff0 || diff1)) {  // (an ulp here and there: does any count see it?)
+                const bool moved0 = diff0 && unwrap_count(fb0, (double)raw[0], c) != unwrap_count(old_fb0, (double)raw[0], c);
+                const bool moved1 = diff1 && unwrap_count(est2[0], (double)raw[1], c) != unwrap_count(est[0], (double)raw[1], c);
+                if (__any(moved0 || moved1))
+                    cy.refuse = true;
+            }
+            est[0] = est2[0];
+            est[1] = est2[1];
+            cy.stat_chain += 1;
+            // a block whose candidates failed is usually followed by more of them (sums wandering around zero):
+            // the next few blocks go straight to the recurrence, then the candidates get another try
+            if (cheap)
+                cy.chain_run -= 1;
+            else if (!warm)
+                cy.chain_run = cy.chain_streak ? 7 : 0;
+            cy.chain_streak = 1;
+        } else {
+            cy.chain_streak = 0;
         }
         if (pass > kMaxUnwrapPasses)
             cy.refuse = true;

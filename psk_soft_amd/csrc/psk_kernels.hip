@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         st->stat_blocks = 0;
         st->stat_extra = 0;
         st->stat_exact = 0;
+        st->stat_chain = 0;
         st->guard = redo ? 2u : 0u;  // 2 = "the guard sent this call here" (statistics)
         sh_head = head;
     }

@@ -79,6 +79,8 @@ struct ChanState {
     uint32_t stat_extra;
     uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
     uint32_t stat_exact;  // blocks whose timing argmax needed the exact double-precision pass
+    uint32_t stat_chain;  // blocks whose LinearFit sums were redone by the reference-order chain (psk_fast_loop.h)
+    uint32_t reserved;
 };
 
 }  // namespace psk

@@ -62,8 +62,12 @@ PSK_DEV double wave_scan_f64(double v)
 // float versions, one instruction a step: the DPP source is folded into the add / max, and for
 // the two cross-row steps the rows masked off simply keep their value (the compiler's own
 // lowering needs a zeroed temporary and a separate add there).  Written as asm because that
-// folding is not reachable from the builtins; the s_nop's are the two wait states a DPP read
-// needs after a VALU write of the same register.
+// folding is not reachable from the builtins.  hipcc pads no hazard whose producer or consumer
+// sits inside an asm statement, so every wait state is in the strings: a DPP instruction reads a
+// register two wait states after its VALU write at the earliest, a v_readlane one; each statement
+// opens with `s_nop 1` (the compiler may have scheduled the producer of the operand right in
+// front) and closes with `s_nop 1` (the consumer right behind may be a DPP instruction or a
+// v_readlane).  tools/isa_hazards.py scans the built ISA for violations of these rules.
 #define PSK_DPP_STEP(op, ctl) op " %0, %0, %0 " ctl
 #define PSK_DPP_ROW1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #define PSK_DPP_ROW2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
@@ -71,36 +75,16 @@ PSK_DEV double wave_scan_f64(double v)
 #define PSK_DPP_ROW8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #define PSK_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define PSK_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+}  // namespace psk
+// N independent scans interleaved step by step, ONE asm statement per N (generated:
+// tools/gen_wave_scan.py): wave_scan_f32_multi(float (&v)[N]), N = 1 .. 32
+#include "psk_wave_scan_gen.h"
+namespace psk {
 PSK_DEV float wave_scan_f32(float v)
 {
-    asm volatile("s_nop 1\n\t" PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW1) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW2) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW4) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_ROW8) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_BC15) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_add_f32_dpp", PSK_DPP_BC31)
-                 : "+v"(v));
-    return v;
-}
-// N independent scans, interleaved step by step: with N >= 3 the other chains fill the wait states
-template <int N>
-PSK_DEV void wave_scan_f32_multi(float (&v)[N])
-{
-#define PSK_SCAN_LEVEL(ctl, first)                                                            \
-    _Pragma("unroll") for (int i = 0; i < N; i++)                                             \
-    {                                                                                         \
-        if (first || N < 3) /* (the compiler may place the producer of v[i] right before) */  \
-            asm volatile("s_nop 1\n\t" PSK_DPP_STEP("v_add_f32_dpp", ctl) : "+v"(v[i]));      \
-        else                                                                                  \
-            asm volatile(PSK_DPP_STEP("v_add_f32_dpp", ctl) : "+v"(v[i]));                    \
-    }
-    PSK_SCAN_LEVEL(PSK_DPP_ROW1, true)
-    PSK_SCAN_LEVEL(PSK_DPP_ROW2, false)
-    PSK_SCAN_LEVEL(PSK_DPP_ROW4, false)
-    PSK_SCAN_LEVEL(PSK_DPP_ROW8, false)
-    PSK_SCAN_LEVEL(PSK_DPP_BC15, false)
-    PSK_SCAN_LEVEL(PSK_DPP_BC31, false)
-#undef PSK_SCAN_LEVEL
+    float a[1] = {v};
+    wave_scan_f32_multi(a);
+    return a[0];
 }
 // max over the wave of non-negative values: lanes without a source read 0, so the running
 // maximum of lane 63 is the wave maximum
@@ -111,7 +95,7 @@ PSK_DEV float wave_max_f32(float v)
                  PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW4) "\n\ts_nop 1\n\t"
                  PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_ROW8) "\n\ts_nop 1\n\t"
                  PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_BC15) "\n\ts_nop 1\n\t"
-                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_BC31)
+                 PSK_DPP_STEP("v_max_f32_dpp", PSK_DPP_BC31) "\n\ts_nop 1"
                  : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
@@ -281,22 +265,63 @@ PSK_DEV void load_symbol(const XView &X, uint64_t tau, bool valid, float2 (&x)[S
 // ---------------------------------------------------------------------------------
 // LinearFit pieces shared by both kernels
 // ---------------------------------------------------------------------------------
-// LinearFit::reset() tail (cpp/psk_soft.cpp:110-122) on `len` values y(j), wave-parallel:
-// ySum = sum y_j, xySum = sum fl32(fl32(j*xdelta)*y_j) accumulated in double.
+// LinearFit::reset() tail (cpp/psk_soft.cpp:110-122) on `len` values y(j):
+// ySum = sum y_j, xySum = sum fl32(fl32(j*xdelta)*y_j), both accumulated in double in the order j = 0, 1, ...
+// The addends are float-valued.  Wave-parallel partial sums give the reference's bits whenever no
+// addition rounds at all, which is certain while 24 + (exponent spread of the non-zero addends) +
+// log2(len) + 1 <= 53; that is the case for any sane window, and is checked here.  Otherwise every lane
+// runs the reference's loop (the values come out of LDS as broadcasts; a few microseconds, once per call).
+PSK_DEV void addend_track(float v, unsigned &umax, unsigned &umin1)
+{
+    const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;  // a zero constrains neither bound
+    umax = b > umax ? b : umax;
+    umin1 = (b - 1u) < umin1 ? (b - 1u) : umin1;
+}
+PSK_DEV bool addends_order_free(unsigned umax, unsigned umin1, uint32_t len)
+{
+    umax = wave_max_u32(umax);
+    umin1 = wave_min_u32(umin1);
+    if (umin1 == 0xFFFFFFFFu)
+        return true;  // all zero
+    if (umax >= 0x7F800000u)
+        return false;  // inf / NaN
+    int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
+    emax = emax < 1 ? 1 : emax;
+    emin = emin < 1 ? 1 : emin;
+    const int terms_log2 = 32 - __builtin_clz(len | 1u);
+    return 24 + (emax - emin) + terms_log2 + 1 <= 53;
+}
 template <class YAt>
 PSK_DEV void fit_rebuild_sums(YAt y_at, uint32_t len, float xdelta, double &ySum, double &xySum)
 {
     const int lane = threadIdx.x & 63;
     double ys = 0.0, xys = 0.0;
+    unsigned ymax = 0u, ymin1 = 0xFFFFFFFFu, tmax = 0u, tmin1 = 0xFFFFFFFFu;
     for (uint32_t j = lane; j < len; j += kWave) {
         float y = y_at(j);
         ys += (double)y;
         float jx = (float)j * xdelta;
         float jxy = jx * y;
         xys += (double)jxy;
+        addend_track(y, ymax, ymin1);
+        addend_track(jxy, tmax, tmin1);
     }
     ySum = wave_sum_f64(ys);
     xySum = wave_sum_f64(xys);
+    const bool free_y = addends_order_free(ymax, ymin1, len), free_t = addends_order_free(tmax, tmin1, len);
+    if (!(free_y && free_t)) {  // (wave-uniform)
+        ys = 0.0, xys = 0.0;
+#pragma unroll 1
+        for (uint32_t j = 0; j < len; j++) {
+            float y = y_at(j);
+            ys += (double)y;
+            float jx = (float)j * xdelta;
+            float jxy = jx * y;
+            xys += (double)jxy;
+        }
+        ySum = ys;
+        xySum = xys;
+    }
 }
 
 // ---------------------------------------------------------------------------------

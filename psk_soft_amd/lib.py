@@ -88,11 +88,13 @@ class Stats(ctypes.Structure):
         ("unwrap_extra_passes", ctypes.c_uint64),
         ("unwrap_blocks", ctypes.c_uint64),
         ("timing_exact_blocks", ctypes.c_uint64),
+        ("fit_chain_blocks", ctypes.c_uint64),
     ]
 
 
 # every symbol include/psk_soft_hip.h declares
 EXPORTS = (
+    "psk_soft_get_channel_stats",
     "psk_soft_probe_read_ms",
     "psk_soft_set_option",
     "psk_soft_host_alloc",
@@ -151,6 +153,7 @@ def load():
     L.psk_soft_process_host.argtypes = [vp, u32, u32, ctypes.POINTER(Packet), ctypes.POINTER(Output)]
     L.psk_soft_synchronize.argtypes = [vp]
     L.psk_soft_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.psk_soft_get_channel_stats.argtypes = [vp, u32, u32, ctypes.POINTER(Stats)]
     L.psk_soft_set_force_sequential.argtypes = [vp, i32]
     L.psk_soft_set_option.argtypes = [vp, i32, i32]
     L.psk_soft_state_bytes.argtypes = [vp]
@@ -369,6 +372,12 @@ class Handle:
         s = Stats()
         _check(self._L.psk_soft_get_stats(self._h, ctypes.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def channel_stats(self, ch0=0, nch=None):
+        nch = self.n_channels - ch0 if nch is None else nch
+        arr = (Stats * nch)()
+        _check(self._L.psk_soft_get_channel_stats(self._h, ch0, nch, arr))
+        return [{k: getattr(s, k) for k, _ in Stats._fields_} for s in arr]
 
     def export_state(self, ch):
         n = int(self._L.psk_soft_state_bytes(self._h))
