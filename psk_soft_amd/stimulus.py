@@ -62,14 +62,17 @@ def pulse_shape(S):
     return 0.2 + 0.8 * np.sin(np.pi * (j + 0.9) / (S + 1.3))
 
 
-def synth_channel(channel, M, S, n_complex, sigma=0.01, cfo_max=1e-3, dtype=np.float32):
-    """One channel of the section-8(d) workload as interleaved I/Q (length 2*n_complex)."""
+def synth_channel(channel, M, S, n_complex, sigma=0.01, cfo_max=1e-3, dtype=np.float32, cfo=None):
+    """One channel of the section-8(d) workload as interleaved I/Q (length 2*n_complex).
+    cfo: M * (carrier phase advance per symbol) given outright instead of drawn from [-cfo_max, cfo_max]."""
     g = np.random.Generator(np.random.Philox(key=SEED_BASE + int(channel)))
     n_sym = -(-n_complex // S)
     k = g.integers(0, M, size=n_sym)
     phi0 = g.uniform(0.0, 2 * np.pi / M)
     gain = g.uniform(0.5, 2.0)
     dphi = g.uniform(-cfo_max, cfo_max) / M  # M * dphi per symbol in [-cfo_max, cfo_max]
+    if cfo is not None:
+        dphi = float(cfo) / M
     sym_phase = 2 * np.pi * k / M + phi0
     t = np.arange(n_sym * S, dtype=np.float64)
     ph = np.repeat(sym_phase, S) + dphi * (t / S)

@@ -1,8 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
 
-Bar (BASELINE.json north_star): bits and sampleIndex bit-exact; soft symbols and phase
-within 1e-5 relative (max |delta| / max |reference|).  Same packetisation on both sides
-(the reference's float outputs depend on it)."""
+Bar (BASELINE.json north_star): bits and sampleIndex bit-exact; soft symbols and phase within 1e-5
+relative.  What the tests assert is stricter: every float of the soft and phase streams has the oracle's
+BITS (assert_parity).  Same packetisation on both sides (the reference's float outputs depend on it,
+SURVEY.md quirk Q2)."""
 import random
 
 import numpy as np
@@ -37,17 +38,25 @@ def run_gpu(h, ch, iq, xdelta, packet=None):
 
 
 def assert_parity(got, ref, ctx=""):
+    """bits and sampleIndex identical; soft and phase BIT-identical too (uint32 equality of every finite value,
+    same non-finite pattern): the kernels restate the reference's arithmetic rounding for rounding, including
+    the order of additions of LinearFit's running sums, so nothing is left for a tolerance to absorb."""
     assert got["bits"].size == ref["bits"].size and got["index"].size == ref["index"].size, ctx
     assert np.array_equal(got["bits"], ref["bits"]), ctx + " bits differ at %s" % np.nonzero(got["bits"] != ref["bits"])[0][:5]
     assert np.array_equal(got["index"], ref["index"]), ctx + " sampleIndex differs"
     for k in ("soft", "phase"):
-        a, b = got[k].astype(np.float64), ref[k].astype(np.float64)
+        a, b = np.ascontiguousarray(got[k], np.float32), np.ascontiguousarray(ref[k], np.float32)
         assert a.size == b.size, ctx
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin), ctx + " non-finite pattern differs on " + k
+        assert np.array_equal(np.isnan(a), np.isnan(b)), ctx + " NaN pattern differs on " + k
         if fin.any():
-            err = np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
-            assert err <= TOL, "%s %s rel err %g" % (ctx, k, err)
+            ua, ub = a.view(np.uint32)[fin], b.view(np.uint32)[fin]
+            if not np.array_equal(ua, ub):
+                d = np.nonzero(ua != ub)[0]
+                err = np.abs(a[fin].astype(np.float64) - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
+                raise AssertionError("%s %s: %d of %d values differ in their bits (first at %d: %.9g vs %.9g), rel err %g"
+                                     % (ctx, k, d.size, ua.size, d[0], a[fin][d[0]], b[fin][d[0]], err))
 
 
 def oracle_run(oracle_mod, iq, props, xdelta=0.01, packet=None):
@@ -423,16 +432,9 @@ def test_random_configuration_sweep(oracle_mod):
             ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
         g = {k: np.concatenate(v) for k, v in got[c].items()}
         r = {k: np.concatenate(v) for k, v in ref.items()}
-        assert np.array_equal(g["index"], r["index"]), (c, props[c])
         assert g["bits"].size == r["bits"].size
         n_bitdiff += int((g["bits"] != r["bits"]).sum())
-        for key in ("soft", "phase"):
-            a, b = g[key].astype(np.float64), r[key].astype(np.float64)
-            fin = np.isfinite(b)
-            assert np.array_equal(np.isfinite(a), fin), (c, props[c], key)
-            if fin.any():
-                err = np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
-                assert err <= TOL, (c, props[c], key, err)
+        assert_parity(g, r, "channel %d %s" % (c, props[c]))
     assert n_bitdiff == 0
     h.close()
 
@@ -491,13 +493,7 @@ def test_noisy_unwrap_fixed_point(oracle_mod):
         got = run_gpu(h, 0, iq, 0.01)
         st = h.stats()
         assert st["channels_fast"] == 1 and st["unwrap_extra_passes"] > 0, st
-        # noisy symbols sit near decision boundaries: compare the float streams and sampleIndex,
-        # and require the bit streams to agree except where the reference symbol is within 1e-5 of a boundary
-        assert np.array_equal(got["index"], ref["index"])
-        for k in ("soft", "phase"):
-            err = np.abs(got[k].astype(np.float64) - ref[k]).max() / np.abs(ref[k]).max()
-            assert err <= TOL, (M, k, err)
-        assert (got["bits"] != ref["bits"]).mean() < 1e-3
+        assert_parity(got, ref, "low SNR M=%d sigma=%g" % (M, sigma))
         h.close()
 
 
@@ -864,3 +860,40 @@ def test_randomised_streams(oracle_mod, monkeypatch):
 
     monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "3", "160", "7"])
     assert fuzz_gpu.main() == 0
+
+
+@pytest.mark.parametrize("S,M,n", [(8, 4, 50), (10, 8, 50), (8, 2, 200), (8, 4, 10), (5, 4, 300), (12, 8, 50)])
+def test_large_phase_estimate_is_bit_identical(oracle_mod, S, M, n):
+    """LinearFit::xySum depends on the ORDER of its additions at the 2^-53 level (cpp/psk_soft.cpp:70-79:
+    xdelta*ySum is a rounded product).  A kernel that sums the same terms in another order flips the float
+    rounding of phaseEstimate now and then; one ulp of the estimate is 6e-5 rad beyond 512 rad, i.e. above 1e-5
+    on the soft symbols -- the round-1 kernel's known deviation.  Here the estimate runs to +-700 ... 2400 rad
+    inside single calls (the reference only wraps it at the end of a call, :592-603), several channels per
+    case with carrier offsets of both signs, two calls each: every float must have the reference's bits."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    nsym = 12000
+    N = nsym * S
+    chans = []
+    for i, cfo in enumerate((0.06, -0.1, 0.2, -0.2, 0.13, -0.17)):
+        iq = synth_channel(900 + 31 * i + S, M, S, 2 * N, cfo=cfo, sigma=0.02)
+        chans.append(iq)
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n)
+    h = _handle(len(chans))
+    h.configure(0, [props] * len(chans))
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in chans]
+    for k in range(2):
+        res = h.process_host(0, [dict(data=x[2 * k * N : 2 * (k + 1) * N], xdelta=0.01, sriChanged=(k == 0)) for x in chans])
+        for c in range(len(chans)):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    st = h.stats()
+    h.close()
+    assert st["channels_fast"] == len(chans), st
+    peak = 0.0
+    for c, x in enumerate(chans):
+        ref = oracle_run(oracle_mod, x, props, packet=N)
+        g = {k: np.concatenate(v) for k, v in got[c].items()}
+        assert_parity(g, ref, "large-estimate S=%d M=%d n=%d ch=%d" % (S, M, n, c))
+        peak = max(peak, float(np.abs(ref["phase"]).max()))
+    assert peak > 700.0, peak  # the regime this test is about was reached

@@ -2,7 +2,7 @@
 tests/test_gpu_parity.py).  Every round draws a batch of channels with random properties, signal
 shapes and packetisations, random property changes / resets between calls, runs it through the C ABI
 and through the oracle, and reports every channel whose four output streams do not match
-(bits / sampleIndex exactly, soft / phase within 1e-5 relative).
+(bits / sampleIndex exactly; soft / phase exactly too -- PSK_FUZZ_STRICT=0 relaxes that to 1e-5 relative).
 
 usage (GPU box): python tools/fuzz_gpu.py [rounds] [channels] [seed]
 """
@@ -17,6 +17,7 @@ from oracle import pyoracle as po  # noqa: E402
 from psk_soft_amd import lib as pl  # noqa: E402
 
 TOL = 1e-5
+STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
 # PSK_FUZZ_S / PSK_FUZZ_A: comma-separated lists that replace the default draws (to aim a run at some instantiations)
 S_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_S"].split(",")] if os.environ.get("PSK_FUZZ_S") else (
@@ -64,6 +65,8 @@ def close(a, b):
         err = np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-30)
         if err > TOL:
             return False, "rel err %g" % err
+        if STRICT and not np.array_equal(a[fin], b[fin]):  # (float32 values widened: equal doubles = equal floats, +-0 aside)
+            return False, "bits differ in %d values (rel err %g)" % (int((a[fin] != b[fin]).sum()), err)
     return True, ""
 
 
