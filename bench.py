@@ -12,6 +12,11 @@ and the max-over-ranks of the elapsed time.
 
 prints ONE JSON line on rank 0, with `roofline` (HBM read roofline of the wave-scan
 kernel) and `cpu_baseline` (the CPU oracle timed on this node's host cores, N=1 only).
+
+N > 1: one process per GPU.  Under a launcher (torchrun: WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* in the
+environment) this process is one rank.  Started plainly with --gpus N > 1 it is the launcher itself: before
+anything touches a GPU it starts N fresh child processes of this script, one per device, with those variables
+set, relays rank 0's JSON line and exits with the worst child status.
 """
 import argparse
 import ctypes
@@ -47,7 +52,12 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="amplitude factor applied to the whole stimulus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall seconds of the CPU baseline sample")
-    ap.add_argument("--check", action="store_true", help="verify a few channels against the oracle after the run")
+    ap.add_argument("--check", dest="check", action="store_true", default=True,
+                    help="replay two channels of the run through the oracle afterwards and compare all four streams (default)")
+    ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_CHANNELS",
+                    help="strong scaling: TOTAL_CHANNELS channels shared by the ranks (BASELINE configs[3]: "
+                         "--M 8 --S 10 --strong 32768) instead of --channels per rank")
     ap.add_argument("--chain-hist", action="store_true", help="per-channel histogram of fit_chain_blocks of the last step (to stderr)")
     return ap.parse_args()
 
@@ -107,7 +117,22 @@ def cpu_baseline(iq_host, M, S, A, n, wall_budget):
         one.service(iq_host[0], 0.01, sriChanged=(done1 == 0))
         done1 += n_complex
     dt1 = time.perf_counter() - t1
+    # BASELINE configs[0] as specified: BPSK, 8 samples per baud, ONE channel, one
+    # serviceFunction call over 2^20 complex samples, one thread (the oracle's serviceFunction-shaped component)
+    from psk_soft_amd.stimulus import synth_channel
+
+    x0 = synth_channel(0, 2, 8, 1 << 20)
+    c0 = po.OracleComponent()
+    c0.samplesPerBaud, c0.constelationSize, c0.numAvg, c0.phaseAvg = 8, 2, 100, 50
+    c0.service(x0[: 2 * 65536], 0.01, sriChanged=True)  # (pages in, first-call resets done)
+    t2 = time.perf_counter()
+    r0 = c0.service(x0, 0.01, sriChanged=False)
+    dt2 = time.perf_counter() - t2
+    config0 = {"workload": "BPSK, samplesPerBaud=8, 1 channel, one call of 2^20 complex samples, one thread",
+               "value": (1 << 20) / dt2 / 1e6, "unit": "complex IQ Msamples/s", "cores": 1, "kind": "port",
+               "symbols_out": int(r0.phase.size)}
     return {
+        "config0": config0,
         "single_thread_value": done1 / dt1 / 1e6,
         "value": total / dt / 1e6,
         "unit": "complex IQ Msamples/s",
@@ -118,8 +143,89 @@ def cpu_baseline(iq_host, M, S, A, n, wall_budget):
     }
 
 
+def dry_rank(a):
+    """PSK_BENCH_DRY=1 (CPU rehearsal of the N > 1 path, tests/test_distributed_gloo.py): the same process group,
+    barriers, sharding and reductions as a real run, control-plane-only handles (PSK_SOFT_DEVICE_NONE: every
+    call is planned, nothing is computed), no GPU.  The line it prints is marked "dry": its rate means nothing."""
+    import torch.distributed as dist
+
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.distributed import max_over_ranks, shard_channels, sum_over_ranks
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(os.environ.get("PSK_BENCH_BACKEND", "gloo"))
+    C = shard_channels(a.strong, world, rank)[1] if a.strong else a.channels
+    h = pl.Handle(C, device=pl.DEVICE_NONE)
+    h.configure_all(samplesPerBaud=a.S, constelationSize=a.M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)
+    pk = [dict(n_floats=2 * a.nsamp, xdelta=0.01, sriChanged=False)] * C
+    n_sym = 0
+    for _ in range(a.warmup):
+        h.plan_only(0, pk)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        n_sym = sum(r["n_symbols"] for r in h.plan_only(0, pk))
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    total = int(sum_over_ranks(C * a.nsamp, dist if world > 1 else None))
+    sym = int(sum_over_ranks(n_sym, dist if world > 1 else None))
+    if rank == 0:
+        print(json.dumps({"metric": "complex IQ Msamples/s, QPSK 8 sps, 4096 ch; % HBM roofline at 1/2/4/8 GPUs", "dry": True,
+                          "value": total * a.steps / elapsed / 1e6, "unit": "complex IQ Msamples/s (planned only, not computed)",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "scaling": "strong" if a.strong else "weak",
+                          "channels_total": total // a.nsamp, "symbols_per_step": sym}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+def launch_ranks(a):
+    """--gpus N > 1 without a launcher: start N ranks of this script, one per GPU (never after this process has
+    touched a GPU: a child inherits nothing but the environment)."""
+    import socket
+    import subprocess
+
+    n = a.gpus
+    if os.environ.get("PSK_BENCH_DRY") != "1":
+        import torch  # (device_count() does not initialise the GPU)
+
+        visible = torch.cuda.device_count()
+        if n > visible and os.environ.get("PSK_BENCH_SHARE_GPU") != "1":  # (rehearsal: several gloo ranks on one GPU)
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (n, visible))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc:
+        raise SystemExit("bench.py: a rank failed (exit status %d)" % rc)
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        raise SystemExit("bench.py: rank 0 did not report %d ranks" % n)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)
+    if os.environ.get("PSK_BENCH_DRY") == "1":
+        return dry_rank(a)
     import torch
 
     from psk_soft_amd import lib as pl
@@ -144,7 +250,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if world != a.gpus and "WORLD_SIZE" in os.environ and a.gpus != 1:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (a.gpus, world))
     C, N, S, M = a.channels, a.nsamp, a.S, a.M
+    if a.strong:  # a fixed total, shared: this rank's contiguous block (psk_soft_amd/distributed.py)
+        from psk_soft_amd.distributed import shard_channels
+
+        C = shard_channels(a.strong, world, rank)[1]
     bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
     if a.mixed:
         chan_props = [dict(samplesPerBaud=S, constelationSize=(2, 4, 8)[c % 3], phaseAvg=(10, 50, 200)[(c // 3) % 3],
@@ -237,7 +349,12 @@ def main():
         sys.stderr.write("chain blocks per channel (bins of 16): %s; max %d; channels over 128: %s\n"
                          % (sorted(hist.items()), max(cs), [i for i, v in enumerate(cs) if v > 128][:20]))
 
-    samples_per_step = C * N * world
+    if world > 1:  # (strong scaling: ranks may own one channel more or less)
+        from psk_soft_amd.distributed import sum_over_ranks
+
+        samples_per_step = int(sum_over_ranks(C * N, dist, red_dev))
+    else:
+        samples_per_step = C * N
     value = samples_per_step * a.steps / elapsed / 1e6
     alg_read_bytes = 8.0 * C * N  # 8 B per complex input sample
     alg_write_bytes = C * n_out * (8 + 4 + 2 + 2 * bpb)
@@ -260,7 +377,7 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if a.strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -282,6 +399,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": "profiles/traffic_latest.json: PMC counters (2*FETCH_SIZE + WRITE_SIZE) of a profiled run of this "
+                              "configuration, a constant of the build, not a measurement of this run" if traffic else None,
             "kernel": "psk_fast_kernel<%d>" % S,
             "algorithmic_read_bytes_per_launch": alg_read_bytes,
             "algorithmic_write_bytes_per_launch": alg_write_bytes,
@@ -305,7 +424,7 @@ def main():
         # replay channel 0 and C-1 through the oracle with the same packetisation
         import numpy as np
 
-        worst = 0.0
+        worst, same = 0.0, True
         for c in (0, C - 1):
             comp = po.OracleComponent()
             for kk, vv in chan_props[c].items():
@@ -315,11 +434,15 @@ def main():
             for k in range(a.warmup + a.steps):
                 r = comp.service(x, 0.01, sriChanged=False)
             gs = soft[c, : 2 * n_out].cpu().numpy()
+            gp = phase[c, :n_out].cpu().numpy()
             gb = bits[c, : {2: 1, 4: 2, 8: 3}.get(chan_props[c]["constelationSize"], 0) * n_out].cpu().numpy()
             gi = sidx[c, :n_out].cpu().numpy()
             assert np.array_equal(gb, r.bits) and np.array_equal(gi, r.index), "bit/index mismatch on channel %d" % c
             worst = max(worst, float(np.abs(gs - r.soft).max() / np.abs(r.soft).max()))
-        res["check"] = {"channels": [0, C - 1], "bits_index_exact": True, "soft_max_rel_err": worst}
+            same = same and np.array_equal(gs.view(np.uint32), np.ascontiguousarray(r.soft, np.float32).view(np.uint32)) \
+                and np.array_equal(gp.view(np.uint32), np.ascontiguousarray(r.phase, np.float32).view(np.uint32))
+        res["check"] = {"channels": [0, C - 1], "calls_replayed": a.warmup + a.steps, "bits_index_exact": True,
+                        "soft_max_rel_err": worst, "soft_phase_bit_identical": bool(same)}
 
     if rank == 0:
         print(json.dumps(res))

@@ -185,6 +185,15 @@ psk_soft_status psk_soft_set_force_sequential(psk_soft_handle_t *h, int on);
 void *psk_soft_host_alloc(size_t bytes);
 void psk_soft_host_free(void *p);
 
+/* Device (HBM) buffers on the handle's GPU for callers that keep packets and results resident and have no HIP
+ * runtime of their own to allocate them with (hipMalloc / hipFree / hipMemcpy behind the handle's device; the
+ * copies are synchronous).  A host that already owns device memory -- torch tensors, its own hipMalloc --
+ * passes those pointers to psk_soft_process_device directly and never needs these. */
+void *psk_soft_device_alloc(psk_soft_handle_t *h, size_t bytes);
+void psk_soft_device_free(psk_soft_handle_t *h, void *p);
+psk_soft_status psk_soft_device_upload(psk_soft_handle_t *h, void *dev_dst, const void *host_src, size_t bytes);
+psk_soft_status psk_soft_device_download(psk_soft_handle_t *h, void *host_dst, const void *dev_src, size_t bytes);
+
 /* Measurement support ("the empirical ceiling on the box -- a pure float4
  * read-reduce kernel over the same buffer"): reads `bytes` of device memory at `dev_ptr` (16-byte
  * aligned) `reps` times with 16-byte loads, nothing else, and returns the mean duration of one pass in

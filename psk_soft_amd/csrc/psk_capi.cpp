@@ -886,6 +886,40 @@ void psk_soft_host_free(void *p)
         (void)hipHostFree(p);
 }
 
+void *psk_soft_device_alloc(psk_soft_handle_t *h, size_t bytes)
+{
+    void *p = nullptr;
+    if (!h || h->dry || !bytes || hipSetDevice(h->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+        g_last_error = "psk_soft_device_alloc: needs a device handle and a size; or hipMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void psk_soft_device_free(psk_soft_handle_t *h, void *p)
+{
+    if (h && !h->dry && p && hipSetDevice(h->device) == hipSuccess)
+        (void)hipFree(p);
+}
+
+psk_soft_status psk_soft_device_upload(psk_soft_handle_t *h, void *dev_dst, const void *host_src, size_t bytes)
+{
+    if (!h || h->dry || !dev_dst || !host_src)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_device_upload: bad arguments");
+    PSK_HIP(hipSetDevice(h->device));
+    PSK_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return PSK_SOFT_OK;
+}
+
+psk_soft_status psk_soft_device_download(psk_soft_handle_t *h, void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!h || h->dry || !host_dst || !dev_src)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_device_download: bad arguments");
+    PSK_HIP(hipSetDevice(h->device));
+    PSK_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return PSK_SOFT_OK;
+}
+
 psk_soft_status psk_soft_peek(const psk_soft_handle_t *h, uint32_t ch, uint64_t *ring_len, uint64_t *index,
                               uint64_t *fit_len)
 {

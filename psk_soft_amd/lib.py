@@ -94,6 +94,10 @@ class Stats(ctypes.Structure):
 
 # every symbol include/psk_soft_hip.h declares
 EXPORTS = (
+    "psk_soft_device_alloc",
+    "psk_soft_device_free",
+    "psk_soft_device_upload",
+    "psk_soft_device_download",
     "psk_soft_get_channel_stats",
     "psk_soft_probe_read_ms",
     "psk_soft_set_option",
@@ -164,6 +168,11 @@ def load():
     L.psk_soft_host_alloc.argtypes = [ctypes.c_size_t]
     L.psk_soft_host_alloc.restype = vp
     L.psk_soft_host_free.argtypes = [vp]
+    L.psk_soft_device_alloc.argtypes = [vp, ctypes.c_size_t]
+    L.psk_soft_device_alloc.restype = vp
+    L.psk_soft_device_free.argtypes = [vp, vp]
+    L.psk_soft_device_upload.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.psk_soft_device_download.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.psk_soft_probe_read_ms.argtypes = [vp, vp, u64, i32, ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
@@ -372,6 +381,25 @@ class Handle:
         s = Stats()
         _check(self._L.psk_soft_get_stats(self._h, ctypes.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    # -- device buffers for callers without a HIP runtime of their own (tests) --------------
+    def device_alloc(self, nbytes):
+        p = self._L.psk_soft_device_alloc(self._h, int(nbytes))
+        if not p:
+            raise PskSoftError(3, self._L.psk_soft_last_error().decode("utf-8", "replace"))
+        return p
+
+    def device_free(self, p):
+        self._L.psk_soft_device_free(self._h, ctypes.c_void_p(p))
+
+    def upload(self, dev_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self._L.psk_soft_device_upload(self._h, ctypes.c_void_p(dev_ptr), arr.ctypes.data, arr.nbytes))
+
+    def download(self, dev_ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        _check(self._L.psk_soft_device_download(self._h, out.ctypes.data, ctypes.c_void_p(dev_ptr), out.nbytes))
+        return out
 
     def channel_stats(self, ch0=0, nch=None):
         nch = self.n_channels - ch0 if nch is None else nch

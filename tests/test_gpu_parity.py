@@ -897,3 +897,92 @@ def test_large_phase_estimate_is_bit_identical(oracle_mod, S, M, n):
         assert_parity(g, ref, "large-estimate S=%d M=%d n=%d ch=%d" % (S, M, n, c))
         peak = max(peak, float(np.abs(ref["phase"]).max()))
     assert peak > 700.0, peak  # the regime this test is about was reached
+
+
+def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels):
+    """C channels through psk_soft_process_device (device-resident packets and output rows, rows on 128-byte
+    boundaries as bench.py lays them out), `calls` = list of samples per call; the channels in check_channels are
+    replayed through the oracle and compared bit for bit on all four streams."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    total = sum(calls)
+    with ThreadPoolExecutor(8) as ex:
+        host = np.stack(list(ex.map(lambda c: synth_channel(70000 + 13 * M + S + c, M, S, total), range(C))))
+    bpb = {2: 1, 4: 2, 8: 3}[M]
+    cap = (max(calls) // S + 2 + 63) // 64 * 64
+    h = pl.Handle(C, device=0)
+    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n_ph)
+    got = {c: dict(soft=[], bits=[], phase=[], index=[]) for c in check_channels}
+    row_in = (2 * max(calls) * 4 + 127) // 128 * 128  # bytes per packet row
+    d_in = h.device_alloc(C * row_in)
+    d_soft, d_phase = h.device_alloc(C * cap * 8), h.device_alloc(C * cap * 4)
+    d_sidx, d_bits = h.device_alloc(C * cap * 2), h.device_alloc(C * cap * 2 * bpb)
+    try:
+        pos = 0
+        for k, n in enumerate(calls):
+            stage = np.zeros((C, row_in // 4), np.float32)
+            stage[:, : 2 * n] = host[:, 2 * pos : 2 * (pos + n)]
+            h.upload(d_in, stage)
+            pk = (pl.Packet * C)()
+            out = (pl.Output * C)()
+            for c in range(C):
+                pk[c].data = d_in + c * row_in
+                pk[c].n_floats = 2 * n
+                pk[c].sri_xdelta = 0.01
+                pk[c].sri_mode = 1
+                pk[c].sriChanged = int(k == 0)
+                pk[c].present = 1
+                out[c].soft = d_soft + c * cap * 8
+                out[c].bits = d_bits + c * cap * 2 * bpb
+                out[c].phase = d_phase + c * cap * 4
+                out[c].sampleIndex = d_sidx + c * cap * 2
+                out[c].cap_symbols = cap
+            h.process_device(0, pk, out)
+            h.synchronize()
+            st = h.stats()
+            assert st["channels_fast"] == C and st["channels_sequential"] == 0, st
+            soft = h.download(d_soft, (C, 2 * cap), np.float32)
+            phase = h.download(d_phase, (C, cap), np.float32)
+            sidx = h.download(d_sidx, (C, cap), np.int16)
+            bits = h.download(d_bits, (C, bpb * cap), np.int16)
+            for c in check_channels:
+                ns = int(out[c].n_symbols)
+                assert int(out[c].n_bits) == bpb * ns
+                got[c]["soft"].append(soft[c, : 2 * ns].copy())
+                got[c]["phase"].append(phase[c, :ns].copy())
+                got[c]["index"].append(sidx[c, :ns].copy())
+                got[c]["bits"].append(bits[c, : bpb * ns].copy())
+            pos += n
+    finally:
+        for p in (d_in, d_soft, d_phase, d_sidx, d_bits):
+            h.device_free(p)
+        h.close()
+    for c in check_channels:
+        o = oracle_mod.OracleComponent()
+        o.samplesPerBaud, o.constelationSize, o.numAvg, o.phaseAvg = S, M, A, n_ph
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        p2 = 0
+        for k, n in enumerate(calls):
+            r = o.service(host[c, 2 * p2 : 2 * (p2 + n)], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+            p2 += n
+        assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, {k: np.concatenate(v) for k, v in ref.items()},
+                      "M=%d S=%d batch of %d, channel %d" % (M, S, C, c))
+
+
+def test_machine_filling_batch_qpsk_s8(oracle_mod):
+    """BASELINE configs[2] at the residency bench.py runs it at: 4096 channels in ONE launch = 16 single-wave
+    workgroups on every CU, the 160 KiB of LDS of a CU exactly full.  Two calls (cold start, then carried state);
+    first, last and every 32nd channel against the oracle, bit for bit."""
+    C = 4096
+    _device_batch(oracle_mod, 4, 8, 100, 50, C, [8192, 8192], sorted(set(range(0, C, 32)) | {C - 1}))
+
+
+def test_machine_filling_batch_8psk_s10(oracle_mod):
+    """The per-GPU shard of BASELINE configs[3]: 4096 channels of 8-PSK at 10 samples per baud, packets that are
+    not a multiple of 10 samples (the symbol clock carries the leftovers from call to call)."""
+    C = 4096
+    _device_batch(oracle_mod, 8, 10, 100, 50, C, [8197, 8191], sorted(set(range(0, C, 32)) | {C - 1}))
