@@ -350,9 +350,9 @@ PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&
 // block are therefore produced so that they ARE the sequential ones, in three steps:
 //   1. candidates, wave-parallel: ySum by a prefix scan (exact whenever the reference's own additions are:
 //      float addends of similar size); xySum by xysum_grid below;
-//   2. fit_sums_verify: every position re-runs the reference's statements on its predecessor's sums and
-//      compares bits.  If all positions agree the candidates are the sequential sums, by induction from the
-//      carried sums -- whatever produced them; nothing else is trusted;
+//   2. a certificate (fit_sums_verify): every position re-runs the reference's statements
+//      on its predecessor's sums and compares bits.  If all positions agree the candidates are the sequential
+//      sums, by induction from the carried sums -- whatever produced them; nothing else is trusted;
 //   3. otherwise fit_sums_chain runs the recurrence itself, lane after lane.
 // ---------------------------------------------------------------------------------------------
 PSK_DEV double pow2_biased(int eb) { return __hiloint2double((int)((unsigned)eb << 20), 0); }
@@ -374,7 +374,7 @@ PSK_DEV bool odd_f64(double n) { return __builtin_amdgcn_fract(n * 0.5) != 0.0; 
 //     it, one block in 16): s_{j-1} is an EVEN multiple of q, so the first rounding is settled locally; the
 //     second one, to multiples of 2, is exact for an even r_j + t_j and a state-dependent tie for an odd one.
 // Anything else (intermediates changing binade, operands off the grid, non-finite values) produces
-// candidates that fit_sums_verify rejects.  tools/model/xysum_grid_model.cpp is the CPU model of this.
+// candidates that do not verify (returns false).  tools/model/xysum_grid_model.cpp is the CPU model of this.
 PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const double (&t)[kR], double (&xs)[kR])
 {
     const double r_first = s_c - read_lane(c[0], 0);          // (wave-uniform, like s_c)
@@ -434,21 +434,25 @@ PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const doubl
     xs[1] = (x0 + a1) * q;
 }
 
-// Do the candidate sums of a block equal the reference's sequential ones?  Every valid position
-// re-runs cpp/psk_soft.cpp:70-79 on its predecessor's sums and compares bits (z = 0 where the window is
-// still filling: the reference skips the pop there, and x - 0 is x).  bit 0: ySum fails, bit 1: xySum fails
-// (a NaN never verifies: its bits differ from case to case; the chain then produces the reference's own).
-PSK_DEV int fit_sums_verify(const bool (&valid)[kR], double ySum_c, double xySum_c, const float (&z)[kR], const float (&y)[kR],
-                            const double (&ySumP)[kR], const double (&c)[kR], const double (&t)[kR],
+// The certificate.  Every valid position re-runs the reference's four statements (cpp/psk_soft.cpp:70, :72, :77,
+// :78) on its predecessor's candidate sums and compares bits: if all positions agree the candidates ARE the
+// sequential sums, by induction from the carried sums, whatever produced them.  The operands are rebuilt here
+// from the block's y and z (cheaper than keeping the candidates' own operands in registers across xysum_grid);
+// where the window is still filling there is no pop (z = 0, and x - 0 is x).  A NaN never verifies (the chain
+// then produces the reference's own).  Returns bit 0: ySum fails, bit 1: xySum fails.
+PSK_DEV int fit_sums_verify(const bool (&valid)[kR], const bool (&steady)[kR], float xd, const float (&sizef)[kR],
+                            double ySum_c, double xySum_c, const float (&z)[kR], const float (&y)[kR],
                             const double (&ySum_l)[kR], const double (&xySum_l)[kR])
 {
-    // (ySumP[1] is ySum_l[0] - z[1] by construction; ySumP[0] came from the scanned base, which must be the
-    // predecessor's candidate sum)
     const double ys_prev = wave_up1(ySum_l[1], ySum_c), xs_prev = wave_up1(xySum_l[1], xySum_c);
-    const bool y0 = same_bits(ys_prev - (double)z[0], ySumP[0]) && same_bits(ySumP[0] + (double)y[0], ySum_l[0]);
-    const bool y1 = same_bits(ySumP[1] + (double)y[1], ySum_l[1]);
-    const bool x0 = same_bits((xs_prev - c[0]) + t[0], xySum_l[0]);
-    const bool x1 = same_bits((xySum_l[0] - c[1]) + t[1], xySum_l[1]);
+    const double p0 = ys_prev - (double)z[0], p1 = ySum_l[0] - (double)z[1];  // ySum after the pop, :70
+    const bool y0 = p0 + (double)y[0] == ySum_l[0], y1 = p1 + (double)y[1] == ySum_l[1];
+    const double c0 = steady[0] ? (double)xd * p0 : 0.0, c1 = steady[1] ? (double)xd * p1 : 0.0;  // :72
+    float t0 = y[0] * sizef[0];  // :78, size before the push
+    t0 = t0 * xd;
+    float t1 = y[1] * sizef[1];
+    t1 = t1 * xd;
+    const bool x0 = (xs_prev - c0) + (double)t0 == xySum_l[0], x1 = (xySum_l[0] - c1) + (double)t1 == xySum_l[1];
     const bool y_ok = __all((y0 || !valid[0]) && (y1 || !valid[1]));
     const bool x_ok = __all((x0 || !valid[0]) && (x1 || !valid[1]));
     return (y_ok ? 0 : 1) | (x_ok ? 0 : 2);
@@ -466,9 +470,9 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
                             const float (&y)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR])
 {
     const double xdd = (double)xd;
-    // operands rebuilt from what the block left behind (the ring holds every y of the window; positions past
-    // the end, and pops where the window is still filling, get zero operands: x - 0 and x + 0 are x, so the
-    // loops need no selects)
+    // operands rebuilt from what the block left behind (the ring holds every y of the window).  Pops where the
+    // window is still filling get zero operands (x - 0 is x); positions past the end run on whatever their lanes
+    // hold: nothing valid comes after them.
     double zz[kR], yy[kR], tt[kR];
     bool steady[kR];
 #pragma unroll
@@ -477,11 +481,11 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
         steady[r] = WARM ? before >= n : true;
         const float sizef = WARM ? (float)(steady[r] ? n - 1 : before) : sizef_steady;
         const float zf = yring[(before - n) & ymask];
-        zz[r] = (valid[r] && steady[r]) ? (double)zf : 0.0;
-        yy[r] = valid[r] ? (double)y[r] : 0.0;
+        zz[r] = steady[r] ? (double)zf : 0.0;
+        yy[r] = (double)y[r];
         float tf = y[r] * sizef;  // :78, size before the push
         tf = tf * xd;
-        tt[r] = valid[r] ? (double)tf : 0.0;
+        tt[r] = (double)tf;
     }
     if (with_y) {
         double ys = ySum_c;
@@ -495,8 +499,8 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
     }
     // xdelta*ySum after each pop, :72 (ySum_l holds the reference's sums by now)
     const double ys_prev = wave_up1(ySum_l[1], ySum_c);
-    const double c0 = (valid[0] && steady[0]) ? xdd * (ys_prev - zz[0]) : 0.0;
-    const double c1 = (valid[1] && steady[1]) ? xdd * (ySum_l[0] - zz[1]) : 0.0;
+    const double c0 = steady[0] ? xdd * (ys_prev - zz[0]) : 0.0;
+    const double c1 = steady[1] ? xdd * (ySum_l[0] - zz[1]) : 0.0;
     double xs = xySum_c;
 #pragma unroll 1
     for (int k = 0; k <= lane_last; k++) {
@@ -578,34 +582,36 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         for (int r = 0; r < kR; r++)
             z[r] = steady[r] ? yring[(before[r] - n) & ymask] : 0.0f;  // yvals.front(), :70
         wave_lds_fence();
-        float t0 = y[0] * sizef[0];  // :78, size before the push
-        t0 = t0 * xd;
-        float t1 = y[1] * sizef[1];
-        t1 = t1 * xd;
-        const double t_d[kR] = {valid[0] ? (double)t0 : 0.0, valid[1] ? (double)t1 : 0.0};
-        // candidate sums, wave-parallel (see xysum_grid), verified on the spot
-        const double dy0 = valid[0] ? (double)y[0] - (double)z[0] : 0.0, dy1 = valid[1] ? (double)y[1] - (double)z[1] : 0.0;
-        const double incl = wave_scan_f64(dy0 + dy1);
-        const double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
-        ySum_l[0] = base + dy0;
-        ySum_l[1] = ySum_l[0] + dy1;
-        double ySumP[kR], c_d[kR];
-        ySumP[0] = base - (double)z[0];  // ySum after the pop, :70
-        ySumP[1] = ySum_l[0] - (double)z[1];
-        c_d[0] = (valid[0] && steady[0]) ? (double)xd * ySumP[0] : 0.0;  // :72
-        c_d[1] = (valid[1] && steady[1]) ? (double)xd * ySumP[1] : 0.0;
-        if (WARM || cheap) {
-            // (the caller runs the recurrence for xySum over this block anyway: any guess will do here)
-            const double cc0 = t_d[0] - c_d[0], cc1 = t_d[1] - c_d[1];
-            const double i2 = wave_scan_f64(cc0 + cc1);
-            const double b2 = cy.xySum + wave_up1(i2, 0.0);
-            xySum_l[0] = b2 + cc0;
-            xySum_l[1] = xySum_l[0] + cc1;
-            rejected = WARM ? 3 : (2 | (fit_sums_verify(valid, cy.ySum, cy.xySum, z, y, ySumP, c_d, t_d, ySum_l, xySum_l) & 1));
-        } else {
-            xysum_grid(lane, cy.xySum, c_d, t_d, xySum_l);
-            rejected = fit_sums_verify(valid, cy.ySum, cy.xySum, z, y, ySumP, c_d, t_d, ySum_l, xySum_l);
+        // candidate sums, wave-parallel (positions past the end need no masking: a prefix sum never looks ahead)
+        {
+            const double dy0 = (double)y[0] - (double)z[0], dy1 = (double)y[1] - (double)z[1];
+            const double incl = wave_scan_f64(dy0 + dy1);
+            const double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
+            ySum_l[0] = base + dy0;
+            ySum_l[1] = ySum_l[0] + dy1;
+            // xdelta*ySum after the pop, :70 and :72
+            const double c_d[kR] = {steady[0] ? (double)xd * (base - (double)z[0]) : 0.0,
+                                    steady[1] ? (double)xd * (ySum_l[0] - (double)z[1]) : 0.0};
+            float t0 = y[0] * sizef[0];  // :78, size before the push
+            t0 = t0 * xd;
+            float t1 = y[1] * sizef[1];
+            t1 = t1 * xd;
+            const double t_d[kR] = {(double)t0, (double)t1};
+            if (WARM || cheap) {
+                // (the caller runs the recurrence for xySum over this block anyway: any guess will do here)
+                const double cc0 = t_d[0] - c_d[0], cc1 = t_d[1] - c_d[1];
+                const double i2 = wave_scan_f64(cc0 + cc1);
+                const double b2 = cy.xySum + wave_up1(i2, 0.0);
+                xySum_l[0] = b2 + cc0;
+                xySum_l[1] = xySum_l[0] + cc1;
+            } else {
+                xysum_grid(lane, cy.xySum, c_d, t_d, xySum_l);
+            }
         }
+        int rej = WARM ? 3 : fit_sums_verify(valid, steady, xd, sizef, cy.ySum, cy.xySum, z, y, ySum_l, xySum_l);
+        if (cheap)
+            rej |= 2;
+        rejected = rej;
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             float m_ = 0.0f, b_;
