@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PSK_SOFT_ABI_VERSION 1
+#define PSK_SOFT_ABI_VERSION 2
 
 typedef enum psk_soft_status {
     PSK_SOFT_OK = 0,

@@ -199,6 +199,10 @@ struct psk_soft_handle {
     int slot = 0;
     bool opt_qpsk_sign_map = false;  // PSK_SOFT_OPT_QPSK_SIGN_BITMAP
     hipStream_t stream = nullptr;
+    // what the call that last used each plan slot worked on, and on which stream (its end is the slot's event)
+    hipStream_t slot_stream[kPlanSlots] = {};
+    uint32_t slot_ch0[kPlanSlots] = {}, slot_nch[kPlanSlots] = {};
+    bool poisoned = false;  // a HIP call failed after kernels of a call were enqueued: host mirror and device state may disagree
     // ingest pipeline of the host-buffer entry point (psk_soft_process_host)
     StageSlot stage[kStageSlots];
     CopyPool *pool = nullptr;
@@ -372,6 +376,9 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
 {
     if (!h || !pkts || !outs || !nch || (uint64_t)ch0 + nch > h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process: bad arguments");
+    if (h->poisoned)
+        return fail(PSK_SOFT_ERR_HIP, "psk_soft_process: an earlier call failed inside HIP after its kernels were enqueued; the "
+                                      "channel states are undefined -- destroy the handle (or import saved states into a new one)");
     // The plans are written straight into the pinned upload slot of this call: wait until the launch
     // that last used the slot has consumed it.  (A refused call does not advance the slot.)
     const int slot = h->slot;
@@ -446,23 +453,32 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         std::snprintf(buf, sizeof buf, "psk_soft_process: channel %u refused (status %d)", ch0 + res.bad, (int)res.st);
         return fail(res.st, buf);
     }
-    // commit
-    if (ch0 == 0 && nch == h->nch)
-        h->ctl.swap(h->ctl_next);
-    else
-        std::memcpy(static_cast<void *>(h->ctl.data() + ch0), next, sizeof(psk::ChanCtl) * nch);
-    for (uint32_t i = 0; i < nch; i++) h->last_mode[ch0 + i] = plans[i].mode;
-    if (h->dry)
+    // The host mirror (ctl) is committed only once everything the call needs has been enqueued: a HIP error
+    // before the first kernel launch leaves the channels untouched; one after it poisons the handle (device
+    // state half advanced, nothing to roll it back with).
+    auto commit = [&]() {
+        if (ch0 == 0 && nch == h->nch)
+            h->ctl.swap(h->ctl_next);
+        else
+            std::memcpy(static_cast<void *>(h->ctl.data() + ch0), next, sizeof(psk::ChanCtl) * nch);
+        for (uint32_t i = 0; i < nch; i++) h->last_mode[ch0 + i] = plans[i].mode;
+    };
+    if (h->dry || !res.any) {
+        commit();
         return PSK_SOFT_OK;
-    const bool any = res.any, any_emit = res.any_emit, any_seq = res.any_seq, any_quiet = res.any_quiet;
+    }
+    const bool any_emit = res.any_emit, any_seq = res.any_seq, any_quiet = res.any_quiet;
     const auto &need_SH = res.need_SH;
     const auto &max_n = res.max_n;
     const auto &max_A = res.max_A;
-    if (!any)
-        return PSK_SOFT_OK;
 
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : h->stream;
-    h->slot = (h->slot + 1) % kPlanSlots;
+    // Calls that touch the same channels must run in order: a call waits for the earlier calls on OTHER streams
+    // whose channel range overlaps its own (same stream: the stream orders them; older calls than the plan slots
+    // remember have completed -- a slot is only reused after its event).
+    for (int k = 0; k < kPlanSlots; k++)
+        if (k != slot && h->ev_used[k] && h->slot_stream[k] != stream && h->slot_ch0[k] < ch0 + nch && ch0 < h->slot_ch0[k] + h->slot_nch[k])
+            PSK_HIP(hipStreamWaitEvent(stream, h->ev[k], 0));
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
                            stream));
     // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
@@ -472,25 +488,38 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         while (y < n_max + 128u) y <<= 1;
         return y;
     };
-    if (any_quiet)
-        PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                 h->lim.fit_cap, ring_floats(res.max_n_quiet, 512u), 0u, stream));
-    // screened timing first; the exact-timing instantiation picks up the calls it refused, the
-    // reference-order kernel (below) the calls both refused
-    for (int exact = 0; exact <= 1; exact++)
-        for (int S : kFastS)
-            for (int H = exact ? 2 : 1; H <= 8; H <<= 1)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
-                if (need_SH[S][H]) {
-                    const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
-                    const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
-                    PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
-                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, stream));
-                }
-    if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
-        PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                h->lim.fit_cap, stream));
-    PSK_HIP(hipEventRecord(h->ev[slot], stream));
+    auto enqueue = [&]() -> psk_soft_status {
+        if (any_quiet)
+            PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+                                     h->lim.fit_cap, ring_floats(res.max_n_quiet, 512u), 0u, stream));
+        // screened timing first; the exact-timing instantiation picks up the calls it refused, the
+        // reference-order kernel (below) the calls both refused
+        for (int exact = 0; exact <= 1; exact++)
+            for (int S : kFastS)
+                for (int H = exact ? 2 : 1; H <= 8; H <<= 1)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
+                    if (need_SH[S][H]) {
+                        const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
+                        const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
+                        PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
+                                                 h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, stream));
+                    }
+        if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
+            PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+                                    h->lim.fit_cap, stream));
+        PSK_HIP(hipEventRecord(h->ev[slot], stream));
+        return PSK_SOFT_OK;
+    };
+    const psk_soft_status est = enqueue();
+    if (est != PSK_SOFT_OK) {
+        h->poisoned = true;
+        return est;
+    }
+    commit();
+    h->slot = (h->slot + 1) % kPlanSlots;
     h->ev_used[slot] = true;
+    h->slot_stream[slot] = stream;
+    h->slot_ch0[slot] = ch0;
+    h->slot_nch[slot] = nch;
     return PSK_SOFT_OK;
 }
 
@@ -795,11 +824,19 @@ psk_soft_status psk_soft_set_force_sequential(psk_soft_handle_t *h, int on)
     return PSK_SOFT_OK;
 }
 
+// A saved channel state: header, control-plane mirror, device state, sample ring (the current buffer), phase history.
+struct StateHeader {
+    uint32_t magic, version;      // "PSKS", PSK_SOFT_ABI_VERSION
+    uint32_t ring_cap, fit_cap;   // the limits the blob was written under: they size its two arrays
+    uint32_t ctl_bytes, state_bytes;
+};
+constexpr uint32_t kStateMagic = 0x534B5350u;  // 'P' 'S' 'K' 'S'
+
 uint64_t psk_soft_state_bytes(const psk_soft_handle_t *h)
 {
     if (!h)
         return 0;
-    return sizeof(psk::ChanCtl) + sizeof(psk::ChanState) + sizeof(float2) * (uint64_t)h->lim.ring_cap +
+    return sizeof(StateHeader) + sizeof(psk::ChanCtl) + sizeof(psk::ChanState) + sizeof(float2) * (uint64_t)h->lim.ring_cap +
            sizeof(float) * (uint64_t)h->lim.fit_cap;
 }
 
@@ -809,6 +846,10 @@ psk_soft_status psk_soft_export_state(psk_soft_handle_t *h, uint32_t ch, void *d
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_export_state: bad arguments");
     uint8_t *p = (uint8_t *)dst;
     std::memset(p, 0, psk_soft_state_bytes(h));
+    StateHeader hd = {kStateMagic, PSK_SOFT_ABI_VERSION, h->lim.ring_cap, h->lim.fit_cap, (uint32_t)sizeof(psk::ChanCtl),
+                      (uint32_t)sizeof(psk::ChanState)};
+    std::memcpy(p, &hd, sizeof hd);
+    p += sizeof hd;
     std::memcpy(p, &h->ctl[ch], sizeof(psk::ChanCtl));
     p += sizeof(psk::ChanCtl);
     if (h->dry)
@@ -827,22 +868,36 @@ psk_soft_status psk_soft_export_state(psk_soft_handle_t *h, uint32_t ch, void *d
 
 psk_soft_status psk_soft_import_state(psk_soft_handle_t *h, uint32_t ch, const void *src, uint64_t bytes)
 {
-    if (!h || !src || ch >= h->nch || bytes < psk_soft_state_bytes(h))
-        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_import_state: bad arguments");
+    if (!h || !src || ch >= h->nch || bytes != psk_soft_state_bytes(h))
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_import_state: bad arguments (the blob must be exactly psk_soft_state_bytes long)");
     const uint8_t *p = (const uint8_t *)src;
-    std::memcpy(&h->ctl[ch], p, sizeof(psk::ChanCtl));
-    p += sizeof(psk::ChanCtl);
-    if (h->dry)
-        return PSK_SOFT_OK;
-    psk_soft_status st = psk_soft_synchronize(h);
-    if (st != PSK_SOFT_OK)
-        return st;
-    PSK_HIP(hipMemcpy(h->d_state + ch, p, sizeof(psk::ChanState), hipMemcpyHostToDevice));
-    p += sizeof(psk::ChanState);
-    float2 *ring = h->d_ring + ((size_t)ch * 2 + h->ctl[ch].ring_src) * h->lim.ring_cap;
-    PSK_HIP(hipMemcpy(ring, p, sizeof(float2) * h->lim.ring_cap, hipMemcpyHostToDevice));
-    p += sizeof(float2) * h->lim.ring_cap;
-    PSK_HIP(hipMemcpy(h->d_yv + (size_t)ch * h->lim.fit_cap, p, sizeof(float) * h->lim.fit_cap, hipMemcpyHostToDevice));
+    StateHeader hd;
+    std::memcpy(&hd, p, sizeof hd);
+    p += sizeof hd;
+    if (hd.magic != kStateMagic || hd.version != PSK_SOFT_ABI_VERSION || hd.ring_cap != h->lim.ring_cap ||
+        hd.fit_cap != h->lim.fit_cap || hd.ctl_bytes != sizeof(psk::ChanCtl) || hd.state_bytes != sizeof(psk::ChanState))
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_import_state: not a state blob of this library version and these limits");
+    // everything the kernels use as an index is checked before anything is overwritten
+    psk::ChanCtl c;
+    std::memcpy(static_cast<void *>(&c), p, sizeof c);
+    p += sizeof c;
+    if (c.ring_src > 1u || c.lf_head >= h->lim.fit_cap || c.lf_len > c.lf_n || c.lf_n >= h->lim.fit_cap || c.lf_len >= h->lim.fit_cap ||
+        c.lf_count > psk::kResyncCount || c.count > psk::kResyncCount ||
+        (uint64_t)c.props.samplesPerBaud * c.props.numAvg > h->lim.ring_cap || c.props.phaseAvg >= h->lim.fit_cap)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_import_state: control state out of range for this handle");
+    if (!h->dry) {
+        psk_soft_status st = psk_soft_synchronize(h);
+        if (st != PSK_SOFT_OK)
+            return st;
+        PSK_HIP(hipSetDevice(h->device));
+        PSK_HIP(hipMemcpy(h->d_state + ch, p, sizeof(psk::ChanState), hipMemcpyHostToDevice));
+        p += sizeof(psk::ChanState);
+        float2 *ring = h->d_ring + ((size_t)ch * 2 + c.ring_src) * h->lim.ring_cap;
+        PSK_HIP(hipMemcpy(ring, p, sizeof(float2) * h->lim.ring_cap, hipMemcpyHostToDevice));
+        p += sizeof(float2) * h->lim.ring_cap;
+        PSK_HIP(hipMemcpy(h->d_yv + (size_t)ch * h->lim.fit_cap, p, sizeof(float) * h->lim.fit_cap, hipMemcpyHostToDevice));
+    }
+    h->ctl[ch] = c;  // (last: a failed copy above leaves the host mirror as it was)
     return PSK_SOFT_OK;
 }
 

@@ -178,7 +178,7 @@ def test_abi_exports_every_declared_symbol():
     L = pl.load()
     for name in pl.EXPORTS:
         assert hasattr(L, name), name
-    assert L.psk_soft_abi_version() == 1
+    assert L.psk_soft_abi_version() == 2
     import os
     import re
 
@@ -212,3 +212,46 @@ def test_options_and_pinned_allocation_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(MemoryError):
             pl.host_alloc(1024, "float32")
+
+
+def test_state_blob_is_validated_on_import():
+    """psk_soft_import_state takes a blob of exactly psk_soft_state_bytes with a header (magic, version, the limits it
+    was written under) and refuses control state that the kernels would use as out-of-range indices; a refused
+    import leaves the channel as it was."""
+    import ctypes
+
+    from psk_soft_amd import lib as pl
+
+    h = pl.Handle(2, device=pl.DEVICE_NONE)
+    h.configure(0, [dict(samplesPerBaud=8, numAvg=100)] * 2)
+    h.plan_only(0, [dict(n_floats=2 * 5000, xdelta=0.01, sriChanged=True)] * 2)
+    blob = h.export_state(0)
+    before = h.peek(1)
+    h.import_state(1, blob)  # a good blob goes in
+    assert h.peek(1) == h.peek(0)
+    bad = bytearray(blob)
+    bad[0] ^= 0xFF  # magic
+    with pytest.raises(pl.PskSoftError):
+        h.import_state(1, bytes(bad))
+    with pytest.raises(pl.PskSoftError):
+        h.import_state(1, blob[:-4])  # short
+    with pytest.raises(pl.PskSoftError):
+        h.import_state(1, blob + b"\0" * 8)  # long
+    other = pl.Handle(1, device=pl.DEVICE_NONE, max_phase_avg=100)  # other limits: other array sizes
+    with pytest.raises(pl.PskSoftError):
+        other.import_state(0, blob)
+    # an index field out of range (ring_src lives in the ChanCtl right behind the 24-byte header; find it by value)
+    ctl_off = 24
+    ctl_len = len(blob) - 24 - 72 - 8 * 16384 - 4 * 513
+    hit = 0
+    for off in range(ctl_off, ctl_off + ctl_len - 3, 4):
+        b2 = bytearray(blob)
+        b2[off : off + 4] = (0x7FFFFFF0).to_bytes(4, "little")
+        h.import_state(1, blob)
+        try:
+            h.import_state(1, bytes(b2))
+        except pl.PskSoftError:
+            hit += 1
+            assert h.peek(1) == h.peek(0)  # untouched by the refused import
+    assert hit >= 3  # lf_head, ring_src, lf_n / lf_len ... are all range-checked
+    assert before is not None
