@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_CHANNELS",
                     help="strong scaling: TOTAL_CHANNELS channels shared by the ranks (BASELINE configs[3]: "
                          "--M 8 --S 10 --strong 32768) instead of --channels per rank")
+    ap.add_argument("--serial-classes", action="store_true", help="--mixed: launch the window classes one after the other (A/B of PSK_SOFT_OPT_CONCURRENT_CLASSES)")
     ap.add_argument("--chain-hist", action="store_true", help="per-channel histogram of fit_chain_blocks of the last step (to stderr)")
     return ap.parse_args()
 
@@ -266,6 +267,8 @@ def main():
         chan_props = [dict(samplesPerBaud=S, constelationSize=M, numAvg=a.numAvg, phaseAvg=a.phaseAvg)] * C
     h = pl.Handle(C, device=dev_index, max_window_samples=max(16384, S * max(p["numAvg"] for p in chan_props)),
                   max_phase_avg=max(512, max(p["phaseAvg"] for p in chan_props)))
+    if a.serial_classes:
+        h.set_option(pl.Handle.OPT_CONCURRENT_CLASSES, 0)
     if a.mixed:
         h.configure(0, chan_props)
     else:

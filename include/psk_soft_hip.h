@@ -170,7 +170,13 @@ psk_soft_status psk_soft_get_channel_stats(psk_soft_handle_t *h, uint32_t ch0, u
  *   constellation diagram at reference cpp/psk_soft.cpp:516-521 describes (A 00, B 01, C 10, D 11,
  *   least significant bit first), instead of the float->bool conversions of :523-526 that make
  *   every QPSK bit 0.  Opt-in; takes effect at the next process call. */
-enum { PSK_SOFT_OPT_QPSK_SIGN_BITMAP = 1 };
+enum {
+    PSK_SOFT_OPT_QPSK_SIGN_BITMAP = 1,
+    /* 1 (default): a batch that mixes window classes (samplesPerBaud, numAvg <= 128 / 256 / 512 / 1024) launches its
+     * classes side by side on streams of the handle, forked off and joined back into the caller's stream; 0: one
+     * after the other on the caller's stream.  No effect on results. */
+    PSK_SOFT_OPT_CONCURRENT_CLASSES = 2
+};
 psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value);
 
 /* Force every channel through the reference-order (sequential) kernel: 1 on, 0 off. */

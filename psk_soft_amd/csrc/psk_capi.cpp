@@ -25,7 +25,7 @@
 #include "psk_soft_hip.h"
 
 namespace psk {
-hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states,
+hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len,
                        hipStream_t stream);
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
@@ -51,6 +51,7 @@ psk_soft_status fail(psk_soft_status st, const std::string &msg)
     } while (0)
 
 constexpr int kPlanSlots = 4;
+constexpr int kAuxStreams = 3;  // side streams for the launches of a batch that mixes window classes (see psk_soft_process_device)
 constexpr int kStageSlots = 3;  // chunks of the host-buffer path in flight (< kPlanSlots)
 
 // Minimal fork-join pool for the host-buffer path: packing packets into pinned memory and
@@ -142,6 +143,7 @@ struct PlanSummary {
     int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
     bool need_SH[33][9] = {};
+    uint32_t cnt_SH[33][9] = {}, cnt_quiet = 0;  // channels per launch: each launch gets a compact list of its own
     // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
     // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
     // ring of r_len positions (even, >= numAvg + 128)
@@ -199,6 +201,9 @@ struct psk_soft_handle {
     int slot = 0;
     bool opt_qpsk_sign_map = false;  // PSK_SOFT_OPT_QPSK_SIGN_BITMAP
     hipStream_t stream = nullptr;
+    hipStream_t aux[kAuxStreams] = {};     // created on first use
+    hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {};
+    int opt_fork = 1;                       // PSK_SOFT_OPT_CONCURRENT_CLASSES
     // what the call that last used each plan slot worked on, and on which stream (its end is the slot's event)
     hipStream_t slot_stream[kPlanSlots] = {};
     uint32_t slot_ch0[kPlanSlots] = {}, slot_nch[kPlanSlots] = {};
@@ -285,9 +290,10 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
         if ((e2 = hipMemset(h->d_ring, 0, ring_b)) != hipSuccess) return bail("hipMemset", e2);
         if ((e2 = hipMemset(h->d_yv, 0, yv_b)) != hipSuccess) return bail("hipMemset", e2);
         for (int s = 0; s < kPlanSlots; s++) {
-            if ((e2 = hipHostMalloc((void **)&h->h_plans[s], sizeof(psk::ChanPlan) * n_channels)) != hipSuccess)
+            // (a slot = the plans of a call followed by the compact channel lists of its launches: one upload)
+            if ((e2 = hipHostMalloc((void **)&h->h_plans[s], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
                 return bail("hipHostMalloc plans", e2);
-            if ((e2 = hipMalloc((void **)&h->d_plans[s], sizeof(psk::ChanPlan) * n_channels)) != hipSuccess)
+            if ((e2 = hipMalloc((void **)&h->d_plans[s], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
                 return bail("hipMalloc plans", e2);
             if ((e2 = hipEventCreateWithFlags(&h->ev[s], hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e2);
@@ -321,6 +327,12 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
             if (sl.stream) (void)hipStreamDestroy(sl.stream);
         }
         delete h->pool;
+        for (int k = 0; k < kAuxStreams; k++) {
+            if (h->aux[k]) (void)hipStreamSynchronize(h->aux[k]);
+            if (h->aux_join[k]) (void)hipEventDestroy(h->aux_join[k]);
+            if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
+        }
+        if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -426,10 +438,12 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                     r.any_emit = true;
                     const int Hh = psk::fast_hist_blocks(p.A);
                     r.need_SH[p.S][Hh] = true;
+                    r.cnt_SH[p.S][Hh]++;
                     if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
                     if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
                 } else {
                     r.any_quiet = true;
+                    r.cnt_quiet++;
                     if (p.lf_n > r.max_n_quiet) r.max_n_quiet = p.lf_n;
                 }
             } else {
@@ -479,8 +493,33 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     for (int k = 0; k < kPlanSlots; k++)
         if (k != slot && h->ev_used[k] && h->slot_stream[k] != stream && h->slot_ch0[k] < ch0 + nch && ch0 < h->slot_ch0[k] + h->slot_nch[k])
             PSK_HIP(hipStreamWaitEvent(stream, h->ev[k], 0));
-    PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], sizeof(psk::ChanPlan) * nch, hipMemcpyHostToDevice,
-                           stream));
+    // compact lists, one per launch, behind the plans: first the channels that emit nothing, then every (S, H)
+    // class in launch order
+    uint32_t *const h_list = reinterpret_cast<uint32_t *>(h->h_plans[slot] + nch);
+    const uint32_t *const d_list = reinterpret_cast<const uint32_t *>(h->d_plans[slot] + nch);
+    uint32_t off_SH[33][9] = {}, off_quiet = 0;
+    {
+        uint32_t run = res.cnt_quiet;
+        for (int S : kFastS)
+            for (int H = 1; H <= 8; H <<= 1) {
+                off_SH[S][H] = run;
+                run += res.cnt_SH[S][H];
+            }
+        uint32_t fill_SH[33][9] = {}, fill_quiet = 0;
+        for (uint32_t i = 0; i < nch; i++) {
+            const psk::ChanPlan &p = plans[i];
+            if (p.mode != psk::PLAN_FAST)
+                continue;
+            if (p.n_out) {
+                const int Hh = psk::fast_hist_blocks(p.A);
+                h_list[off_SH[p.S][Hh] + fill_SH[p.S][Hh]++] = i;
+            } else {
+                h_list[off_quiet + fill_quiet++] = i;
+            }
+        }
+    }
+    PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
+                           hipMemcpyHostToDevice, stream));
     // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
     // the energy ring is dynamic too and every byte of LDS counts towards residency)
     auto ring_floats = [](uint32_t n_max, uint32_t at_least) {
@@ -490,19 +529,58 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     };
     auto enqueue = [&]() -> psk_soft_status {
         if (any_quiet)
-            PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+            PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], d_list + off_quiet, ch0, res.cnt_quiet, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                      h->lim.fit_cap, ring_floats(res.max_n_quiet, 512u), 0u, stream));
-        // screened timing first; the exact-timing instantiation picks up the calls it refused, the
-        // reference-order kernel (below) the calls both refused
-        for (int exact = 0; exact <= 1; exact++)
+        // Per window class (samplesPerBaud, history depth): screened timing first, then the exact-timing
+        // instantiation, which picks up the calls the screening refused; the reference-order kernel (below) takes
+        // the calls both refused.  A batch that mixes classes runs them SIDE BY SIDE: each class is its own
+        // instantiation with its own register and LDS appetite (numAvg <= 128: 16 waves per CU; numAvg 400: 8), and
+        // one after the other each would leave part of the machine idle.  The classes go to side streams forked off
+        // the caller's stream behind the plan upload and joined again in front of the reference-order kernel; the
+        // deepest histories (fewest waves per CU, longest tails) are launched first.
+        struct Cls {
+            int S, H;
+        };
+        Cls cls[33 * 4];
+        int n_cls = 0;
+        for (int H = 8; H >= 1; H >>= 1)
             for (int S : kFastS)
-                for (int H = exact ? 2 : 1; H <= 8; H <<= 1)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
-                    if (need_SH[S][H]) {
-                        const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
-                        const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
-                        PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], ch0, nch, h->d_state, h->d_ring,
-                                                 h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, stream));
-                    }
+                if (need_SH[S][H])
+                    cls[n_cls++] = Cls{S, H};
+        const bool fork = n_cls > 1 && h->opt_fork;
+        if (fork) {
+            if (!h->aux_fork) {
+                PSK_HIP(hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming));
+                for (int k = 0; k < kAuxStreams; k++) {
+                    PSK_HIP(hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking));
+                    PSK_HIP(hipEventCreateWithFlags(&h->aux_join[k], hipEventDisableTiming));
+                }
+            }
+            PSK_HIP(hipEventRecord(h->aux_fork, stream));
+        }
+        int used_aux = 0;
+        for (int i = 0; i < n_cls; i++) {
+            const int S = cls[i].S, H = cls[i].H;
+            // class 0 stays on the caller's stream, the others take the side streams in turn
+            hipStream_t st = stream;
+            if (fork && i > 0) {
+                const int a = (i - 1) % kAuxStreams;
+                st = h->aux[a];
+                if (i - 1 < kAuxStreams) {
+                    PSK_HIP(hipStreamWaitEvent(st, h->aux_fork, 0));
+                    used_aux = i;
+                }
+            }
+            const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
+            const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
+            for (int exact = 0; exact <= (H == 1 ? 0 : 1); exact++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
+                PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
+                                         h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
+        }
+        for (int a = 0; a < used_aux && a < kAuxStreams; a++) {
+            PSK_HIP(hipEventRecord(h->aux_join[a], h->aux[a]));
+            PSK_HIP(hipStreamWaitEvent(stream, h->aux_join[a], 0));
+        }
         if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
             PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                     h->lim.fit_cap, stream));
@@ -812,6 +890,7 @@ psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "null handle");
     switch (option) {
     case PSK_SOFT_OPT_QPSK_SIGN_BITMAP: h->opt_qpsk_sign_map = value != 0; return PSK_SOFT_OK;
+    case PSK_SOFT_OPT_CONCURRENT_CLASSES: h->opt_fork = value != 0; return PSK_SOFT_OK;
     default: return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: unknown option");
     }
 }

@@ -9,7 +9,7 @@
 namespace psk {
 hipError_t PSK_CAT(launch_fast_S, PSK_INST_S, _H, PSK_INST_H, _E, PSK_INST_E)(PSK_FAST_ARGS)
 {
-    return launch_fast_inst<PSK_INST_S, PSK_INST_H, (PSK_INST_E != 0)>(plans, ch0, nch, states, rings, ring_cap, yvs,
+    return launch_fast_inst<PSK_INST_S, PSK_INST_H, (PSK_INST_E != 0)>(plans, list, ch0, nch, states, rings, ring_cap, yvs,
                                                                        fit_cap, y_len, r_len, stream);
 }
 }  // namespace psk

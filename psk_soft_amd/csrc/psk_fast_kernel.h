@@ -22,7 +22,7 @@ PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 
 // (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
 // runs on 1 and leaves 2.
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)
@@ -44,14 +44,16 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
         er.mem = ering_s;
     }
     const int lane = threadIdx.x & 63;
-    const ChanPlan &p = plans[blockIdx.x];
+    // the launch covers the channels of the batch that this instantiation handles: list[workgroup] = index into the batch
+    const uint32_t bi = list[blockIdx.x];
+    const ChanPlan &p = plans[bi];
     if (p.mode != PLAN_FAST)
         return;
     if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV))
         return;
-    if (EXACT && states[ch0 + blockIdx.x].guard != 1u)
+    if (EXACT && states[ch0 + bi].guard != 1u)
         return;  // the screened kernel finished this channel's call
-    const uint32_t ch = ch0 + blockIdx.x;
+    const uint32_t ch = ch0 + bi;
     ChanState *st = &states[ch];
     float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
     const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
 }
 
 #define PSK_FAST_ARGS                                                                                          \
-    const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings, uint32_t ring_cap,    \
+    const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings, uint32_t ring_cap,    \
         float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len, hipStream_t stream
 
 template <int SV, int HV, bool EXACT>
@@ -195,7 +197,7 @@ hipError_t launch_fast_inst(PSK_FAST_ARGS)
     if (!nch)
         return hipSuccess;
     const size_t lds_bytes = sizeof(float) * ((size_t)y_len + (ering_dynamic(SV) ? (size_t)SV * r_len : 0));
-    hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, ch0, states,
+    hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, list, ch0, states,
                        rings, ring_cap, yvs, fit_cap, y_len, r_len);
     return hipGetLastError();
 }

@@ -295,6 +295,16 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
 // repeats until nothing changes.  This is a guess: everything is verified by the exact pass that
 // follows, an overflow of the packed sums or a float near-tie only costs another pass.
 constexpr int kRefineMax = 12;
+#ifndef PSK_CHAIN_RUN
+#define PSK_CHAIN_RUN 7     // blocks that go straight to the chain once it ran on PSK_CHAIN_STREAK + 1 blocks in a row
+#define PSK_CHAIN_STREAK 1
+#endif
+#ifndef PSK_CHAIN_PRIO
+#define PSK_CHAIN_PRIO 2
+#endif
+#ifndef PSK_CHAIN_UNROLL
+#define PSK_CHAIN_UNROLL 4
+#endif
 PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&est)[kR], const float (&raw)[kR],
                            const bool (&valid)[kR], const int (&w_base)[kR], int (&w2)[kR])
 {
@@ -502,13 +512,18 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
     const double c0 = steady[0] ? xdd * (ys_prev - zz[0]) : 0.0;
     const double c1 = steady[1] ? xdd * (ySum_l[0] - zz[1]) : 0.0;
     double xs = xySum_c;
+    const int steps = PSK_CHAIN_UNROLL * ((lane_last + PSK_CHAIN_UNROLL) / PSK_CHAIN_UNROLL);  // (extra steps recompute final values)
 #pragma unroll 1
-    for (int k = 0; k <= lane_last; k++) {
-        const double b = wave_up1(xs, xySum_c);
-        xySum_l[0] = (b - c0) + tt[0];  // :72 and :78
-        xySum_l[1] = (xySum_l[0] - c1) + tt[1];
-        xs = xySum_l[1];
+    for (int k = 0; k < steps; k += PSK_CHAIN_UNROLL) {
+#pragma unroll
+        for (int u = 0; u < PSK_CHAIN_UNROLL; u++) {
+            const double b = wave_up1(xs, xySum_c);
+            xs = ((b - c0) + tt[0] - c1) + tt[1];  // :72 and :78, twice
+        }
     }
+    const double b_fin = wave_up1(xs, xySum_c);
+    xySum_l[0] = (b_fin - c0) + tt[0];
+    xySum_l[1] = xs;
 }
 
 // One block (128 symbols) of the feedback unwrap + LinearFit::next recurrence
@@ -899,10 +914,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     for (int c = 0; c < n_blocks; c++) {
         // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
-        // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %)
+        // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %, touching the next block's
+        // lines with a one-dword load per lane half a block ahead +9 %: the loads in flight are not the limit)
         __builtin_amdgcn_s_setprio(3);
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
         valid[0] = i0 < n_out;
@@ -1113,7 +1130,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         // raised priority through the arithmetic half too: its other work then runs ahead of its neighbours'
         // and the wave keeps pace with them.  There are a handful of them in thousands.)
         if (cy.chain_run)
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(PSK_CHAIN_PRIO);
         else
             __builtin_amdgcn_s_setprio(0);
         // ================= raw phase: arg(pow(sample, M)) (reference cpp/psk_soft.cpp:474) =================
@@ -1141,6 +1158,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
                                    lane_last, r_last, den_last, xavg_last, cheap, rejected);
         }
+#ifdef PSK_ABL_NOCHAIN  /* (ablation builds only: what the chain costs) */
+        rejected = 0;
+#endif
         if (rejected) {
             // The candidates are not the reference's sums (or were not attempted): the recurrence itself, then the
             // estimates from ITS sums.  The unwrap counts were verified against the candidates' estimates, which
@@ -1182,8 +1202,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             if (cheap)
                 cy.chain_run -= 1;
             else if (!warm)
-                cy.chain_run = cy.chain_streak ? 7 : 0;
-            cy.chain_streak = 1;
+                cy.chain_run = cy.chain_streak >= PSK_CHAIN_STREAK ? PSK_CHAIN_RUN : 0;
+            cy.chain_streak += 1;
         } else {
             cy.chain_streak = 0;
         }

@@ -364,20 +364,21 @@ PSK_DECL_S_WIDE(30)
 PSK_DECL_S_WIDE(31)
 PSK_DECL_S_WIDE(32)
 
+// `list` = the nch indices into the batch (plans[], states[ch0 + .]) this launch covers, one workgroup each.
 // S = 0: the channels that emit nothing this call.  Otherwise S in {2,3,4,5,6,7,8,10,12,16}, H in {1,2,4}
 // blocks of window history, exact = 0 (screened timing) / 1 (exact timing, runs on refused calls).
 hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
 {
     if (S == 0)
-        return launch_fast_inst<0, 1, false>(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+        return launch_fast_inst<0, 1, false>(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE(Sv, Hv)                                                                                              \
     if (S == Sv && H == Hv)                                                                                           \
-        return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream) \
-                     : launch_fast_S##Sv##_H##Hv##_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+        return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream) \
+                     : launch_fast_S##Sv##_H##Hv##_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE1(Sv)                                                                                                 \
     if (S == Sv && H == 1)                                                                                            \
         return exact ? hipSuccess                                                                                     \
-                     : launch_fast_S##Sv##_H1_E0(plans, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+                     : launch_fast_S##Sv##_H1_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
 #define PSK_CASE_S(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S(2)
     PSK_CASE_S(3)

@@ -255,6 +255,7 @@ class Handle:
         _check(self._L.psk_soft_fire_listener(self._h, ch, which))
 
     OPT_QPSK_SIGN_BITMAP = 1
+    OPT_CONCURRENT_CLASSES = 2
 
     def set_option(self, option, value):
         _check(self._L.psk_soft_set_option(self._h, int(option), int(value)))
