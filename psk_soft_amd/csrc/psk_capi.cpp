@@ -573,7 +573,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             }
             const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
             const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
-            for (int exact = 0; exact <= (H == 1 ? 0 : 1); exact++)  // (no exact-timing kernel for numAvg <= 128, see launch_fast)
+            for (int exact = 0; exact <= 1; exact++)  // (the exact tier only works on the calls the screened tier left)
                 PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
         }

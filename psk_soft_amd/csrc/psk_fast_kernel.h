@@ -22,7 +22,7 @@ PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 
 // (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
 // runs on 1 and leaves 2.
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)
@@ -114,8 +114,6 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10) ? 4 : 1)) void psk_fast_
     {
         unsigned umax = wave_max_u32(cy.umax);
         unsigned umin1 = wave_min_u32(cy.umin1);
-        if (umax >= 0x7F800000u)
-            cy.refuse = true;  // inf / NaN energy
         if (umin1 != 0xFFFFFFFFu && __any(cy.ambiguous)) {
             int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
             emax = emax < 1 ? 1 : emax;

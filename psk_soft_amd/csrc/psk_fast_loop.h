@@ -65,9 +65,19 @@ struct FastCarry {
 
 // exactness guard bookkeeping: max of the energy bit patterns and min of (bits - 1); a zero
 // energy gives bits 0 / 0xFFFFFFFF and so constrains neither
+// An energy that is inf or NaN (energies carry no sign) is not a question of exactness: the screened tier leaves
+// the call to the exact tier (EXACT_TIER), whose window sums are updated symbol by symbol like the reference's and
+// so take the same values (inf while the sample is in the window, NaN from the moment it leaves, to the end of the
+// call) and decide the same way (argtop_next).
+template <bool EXACT_TIER>
 PSK_DEV void guard_track(FastCarry &cy, float e)
 {
     const unsigned eb = __float_as_uint(e);
+    if (eb >= 0x7F800000u) {
+        if (!EXACT_TIER)
+            cy.refuse = true;
+        return;
+    }
     cy.umax = eb > cy.umax ? eb : cy.umax;
     const unsigned em = eb - 1u;
     cy.umin1 = em < cy.umin1 ? em : cy.umin1;
@@ -294,6 +304,14 @@ PSK_DEV auto block_back(int back, const BlockKeep<S> &cur, const BlockKeep<S> (&
 // the same float formula (so that where nothing moved, the exact count w2 stands), and the step
 // repeats until nothing changes.  This is a guess: everything is verified by the exact pass that
 // follows, an overflow of the packed sums or a float near-tie only costs another pass.
+template <bool WIDE>
+struct WrapInt {
+    typedef int type;
+};
+template <>
+struct WrapInt<true> {
+    typedef long long type;
+};
 constexpr int kRefineMax = 12;
 #ifndef PSK_CHAIN_RUN
 #define PSK_CHAIN_RUN 7     // blocks that go straight to the chain once it ran on PSK_CHAIN_STREAK + 1 blocks in a row
@@ -536,7 +554,9 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
 // least one more position.  WARM = the fit window is still growing somewhere in the block.
 // Returns the number of extra passes; den_last / xavg_last = LinearFit::denominator / xAvg after
 // the block's last valid symbol.
-template <bool WARM>
+// WIDE (the exact tier): numWraps kept as the 64-bit integer the reference has -- an estimate that is NaN or astronomically
+// large (what a non-finite sample leaves behind) unwraps by counts far beyond 2^31, and (long)NaN is LONG_MIN on x86.
+template <bool WARM, bool WIDE>
 PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk,
                       const bool (&valid)[kR], const float (&raw)[kR], const FastCarry &cy,
                       float *yring, uint32_t ymask, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
@@ -571,14 +591,18 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
     // (cpp/psk_soft.cpp:477 with est[s-1] ~ est_carry + slope*s).  Every position guesses on its
     // own, so a noisy sample spoils one guess, not all that follow (guessing by consecutive raw
     // differences did: at 10 dB it needed 9 correction passes a block).  Position 0 is exact.
-    int w[kR];
+    typedef typename WrapInt<WIDE>::type WInt;
+    WInt w[kR];
     {
         // (a guess only: float arithmetic is enough; every count is verified below)
         const float inv2pi = 0.15915494f;
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             const float pred = cy.est + cy.slope * (float)(2 * lane + r);
-            w[r] = (int)__builtin_rintf((pred - raw[r]) * inv2pi);
+            if (WIDE)
+                w[r] = (WInt)unwrap_count(pred, (double)raw[r], (int)q0);
+            else
+                w[r] = (WInt)(int)__builtin_rintf((pred - raw[r]) * inv2pi);
         }
     }
     const double two_pi = PSK_KD(kTwoPi, (int)q0);
@@ -649,16 +673,19 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             if (__all(sure0 && sure1))
                 break;
         }
-        int w2_0 = (int)unwrap_count(est_prev0, (double)raw[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
-        int w2_1 = (int)unwrap_count(est[0], (double)raw[1], (int)q0);
+        WInt w2_0 = (WInt)unwrap_count(est_prev0, (double)raw[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
+        WInt w2_1 = (WInt)unwrap_count(est[0], (double)raw[1], (int)q0);
         const bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
         if (!__any(bad))
             break;
-        int w2[kR] = {w2_0, w2_1};
-        if (!WARM)
+        if constexpr (!WARM && !WIDE) {
+            int w2[kR] = {w2_0, w2_1};
             refine_unwrap(lane, n, est_prev0, est, raw, valid, w, w2);
-        w[0] = w2[0];
-        w[1] = w2[1];
+            w2_0 = w2[0];
+            w2_1 = w2[1];
+        }
+        w[0] = w2_0;
+        w[1] = w2_1;
         if (++pass > kMaxUnwrapPasses)
             break;
     }
@@ -724,9 +751,13 @@ PSK_DEV void argtop_first(ArgTop &t, double W)
 PSK_DEV void argtop_next(ArgTop &t, double W, int k)
 {
     const bool gt = t.best < W;  // std::max_element: first maximum, strict '<' (cpp/psk_soft.cpp:462)
-    const float d = (float)(gt ? W - t.best : t.best - W);
-    // smaller of (gap, d), NaN-propagating: a NaN sum must end up ambiguous
-    const float lo = (d < t.gap || d != d) ? d : t.gap;
+    // A sum that is inf or NaN (a non-finite sample in the window, or one that left it: inf - inf) compares the way
+    // IEEE says, in the reference as here -- a NaN never wins and is never beaten (phase 0 keeps the lead it starts
+    // with, the others are passed over), the first inf beats everything finite: nothing there depends on rounding,
+    // so such a pair is as unambiguous as a pair can be.
+    const bool special = !(__builtin_fabs(W) < (double)__builtin_inff()) || !(__builtin_fabs(t.best) < (double)__builtin_inff());
+    const float d = special ? __builtin_inff() : (float)(gt ? W - t.best : t.best - W);
+    const float lo = d < t.gap ? d : t.gap;
     t.gap = gt ? d : lo;
     t.best = gt ? W : t.best;
     t.k = gt ? k : t.k;
@@ -794,12 +825,12 @@ PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base,
                 continue;
         }
         const float2 ep = *reinterpret_cast<const float2 *>(row + i_prev);
-        guard_track(cy, en.x);
-        guard_track(cy, en.y);
-        guard_track(cy, ep.x);
-        guard_track(cy, ep.y);
-        guard_track(cy, eo0);
-        guard_track(cy, eo1);
+        guard_track<false>(cy, en.x);
+        guard_track<false>(cy, en.y);
+        guard_track<false>(cy, ep.x);
+        guard_track<false>(cy, ep.y);
+        guard_track<false>(cy, eo0);
+        guard_track<false>(cy, eo1);
         // the window ending at the previous block's last position: its positions >= kB - A
         const double Wc = wave_sum_f64((in0 ? (double)ep.x : 0.0) + (in1 ? (double)ep.y : 0.0));
         const double d0 = (double)en.x - (double)eo0, d1 = (double)en.y - (double)eo1;
@@ -860,7 +891,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 for (int k = 0; k < S; k++) {
                     float e = norm_f(x[r][k].x, x[r][k].y);
                     if (EXACT)
-                        guard_track(cy, e);  // zero-filled (absent) symbols are neutral
+                        guard_track<true>(cy, e);  // zero-filled (absent) symbols are neutral
                     hist[h].e[r][k] = e;
                     acc[k] += (double)e;
                 }
@@ -937,7 +968,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             for (int k = 0; k < S; k++) {
                 float e = norm_f(xn[r][k].x, xn[r][k].y);
                 if (EXACT)
-                    guard_track(cy, e);
+                    guard_track<true>(cy, e);
                 cur.e[r][k] = e;
             }
             cur.kp[r] = kpred[r];
@@ -1069,7 +1100,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
                 double incl = wave_scan_f64(d0 + d1);  // exact under the guard (quirk Q8)
                 double W1 = Wc[k] + incl;              // window sum of the lane's second symbol
-                double W0 = W1 - d1;                   // ... and of its first
+                // ... and of its first: the sums before it plus its own difference (W1 - d1 is the same number
+                // while d1 is finite; an inf or NaN entering or leaving the window at the second symbol must not
+                // reach back to the first)
+                double W0 = (Wc[k] + wave_up1(incl, 0.0)) + d0;
                 Wc[k] = read_lane(W1, 63);
                 if (k == 0) {
                     argtop_first(top[0], W0);
@@ -1080,7 +1114,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 }
             }
             {
-                const float mx = (float)__builtin_fmax(valid[0] ? top[0].best : 0.0, valid[1] ? top[1].best : 0.0);
+                // (the largest FINITE sum scales the rounding bound)
+                const double b0 = (valid[0] && __builtin_fabs(top[0].best) < (double)__builtin_inff()) ? top[0].best : 0.0;
+                const double b1 = (valid[1] && __builtin_fabs(top[1].best) < (double)__builtin_inff()) ? top[1].best : 0.0;
+                const float mx = (float)__builtin_fmax(b0, b1);
                 cy.wmax = __builtin_fmaxf(cy.wmax, wave_max_f32(__builtin_fmaxf(mx, 0.0f)) * 1.0000002f);
                 const float bound_abs = 2.0f * drift_bound(c * kB + kB, A) * cy.wmax;
 #pragma unroll
@@ -1137,9 +1174,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         float raw[kR];  // arg(pow(sample, M)): a float (std::arg of complex<float>), widened where the reference widens it
 #pragma unroll
         for (int r = 0; r < kR; r++) {
-            cf32 pw = cpow_uint<false>(s[r], M);
-            if (valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
-                cy.refuse = true;  // overflow / NaN: the reference-order kernel owns __mulsc3 semantics
+            // (the screened tier hands samples whose power is not finite to the exact tier, which carries
+            // libgcc's __mulsc3 recovery: cmul<true>)
+            cf32 pw = cpow_uint<EXACT>(s[r], M);
+            if (!EXACT && valid[r] && !(is_fin(pw.re) && is_fin(pw.im)))
+                cy.refuse = true;
             raw[r] = atan2f_wave(pw.im, pw.re, atab);
         }
 
@@ -1152,10 +1191,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
         const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
         if (!warm) {
-            pass = fit_block<false>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+            pass = fit_block<false, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
                                     lane_last, r_last, den_last, xavg_last, cheap, rejected);
         } else {
-            pass = fit_block<true>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+            pass = fit_block<true, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
                                    lane_last, r_last, den_last, xavg_last, cheap, rejected);
         }
 #ifdef PSK_ABL_NOCHAIN  /* (ablation builds only: what the chain costs) */
@@ -1211,6 +1250,13 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             cy.refuse = true;
         cy.stat_blocks += 1;
         cy.stat_extra += (uint32_t)pass;
+        if constexpr (!EXACT) {
+            // a call this tier cannot finish is the exact tier's from its first symbol on: stop here
+            if (__any(cy.refuse)) {
+                cy.refuse = true;
+                return;
+            }
+        }
 
         // ================= de-rotation and hard decisions (reference cpp/psk_soft.cpp:484-566) =================
         cf32 corr[kR];
@@ -1240,7 +1286,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             ph.im = 1.0f * sn;
             // (__mulsc3's recovery only ever changes a product with an infinite factor: impossible
             // without differential decoding, where smp is a sample whose M-th power was finite)
-            corr[r] = p.diff ? cmul<true>(smp, ph) : cmul<false>(smp, ph);
+            corr[r] = (p.diff || EXACT) ? cmul<true>(smp, ph) : cmul<false>(smp, ph);
         }
 
         // ---- four output streams, two symbols per lane ----

@@ -315,7 +315,7 @@ namespace psk {
 // (numAvg <= 128 has no exact-timing instantiation: its screened kernel settles near-ties itself, and
 // whatever else makes it refuse a call -- non-finite data, the exactness guard -- the exact kernel
 // would refuse too; those calls go straight to the reference-order kernel)
-#define PSK_DECL_S(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
+#define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S(2)
 PSK_DECL_S(3)
 PSK_DECL_S(4)
@@ -346,7 +346,7 @@ PSK_DECL_SH(13, 8)
 PSK_DECL_SH(14, 8)
 PSK_DECL_SH(15, 8)
 PSK_DECL_SH(16, 8)
-#define PSK_DECL_S_WIDE(S) PSK_DECL(S, 1, 0) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
+#define PSK_DECL_S_WIDE(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S_WIDE(17)
 PSK_DECL_S_WIDE(18)
 PSK_DECL_S_WIDE(19)
@@ -379,7 +379,7 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     if (S == Sv && H == 1)                                                                                            \
         return exact ? hipSuccess                                                                                     \
                      : launch_fast_S##Sv##_H1_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
-#define PSK_CASE_S(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
+#define PSK_CASE_S(Sv) PSK_CASE(Sv, 1) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S(2)
     PSK_CASE_S(3)
     PSK_CASE_S(4)
@@ -410,7 +410,7 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     PSK_CASE(14, 8)
     PSK_CASE(15, 8)
     PSK_CASE(16, 8)
-#define PSK_CASE_S_WIDE(Sv) PSK_CASE1(Sv) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
+#define PSK_CASE_S_WIDE(Sv) PSK_CASE(Sv, 1) PSK_CASE(Sv, 2) PSK_CASE(Sv, 4)
     PSK_CASE_S_WIDE(17)
     PSK_CASE_S_WIDE(18)
     PSK_CASE_S_WIDE(19)

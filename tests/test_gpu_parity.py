@@ -459,24 +459,89 @@ def test_exactness_guard_hands_over(oracle_mod):
     h.close()
 
 
-def test_non_finite_samples_take_the_slow_tiers(oracle_mod):
-    """NaN / inf samples: the wave-scan kernels carry no NaN semantics of their own (the
-    screened one not even the general libm routines); such calls must travel down the tiers to the
-    reference-order kernel and come out exactly as the oracle's, non-finite pattern included."""
+def test_non_finite_samples_stay_on_the_wave_scan_kernels(oracle_mod):
+    """NaN / inf samples (the reference has no special case for them, cpp/psk_soft.cpp:445-452: it runs on at its
+    normal speed and puts out what IEEE arithmetic makes of them).  The screened tier hands such a call to the
+    exact-timing tier, whose window sums are updated symbol by symbol like the reference's (inf while the sample
+    sits in the window, NaN for the rest of the call once it has left) and which carries libgcc's complex-multiply
+    recovery and 64-bit unwrap counts ((long)NaN is LONG_MIN on x86): every call comes out with the oracle's bits,
+    non-finite pattern included, and NONE goes to the reference-order kernel -- in round 1 one NaN sample sent its
+    channel there for good, at 150 ms a call."""
     from psk_soft_amd.stimulus import synth_channel
 
-    for M, diff in ((4, 0), (2, 1), (8, 0)):
-        iq = synth_channel(21 + M, M, 8, 1 << 14).copy()
+    for M, diff, S, A in ((4, 0, 8, 100), (2, 1, 8, 100), (8, 0, 8, 100), (4, 0, 10, 100), (4, 0, 8, 300), (8, 1, 5, 40)):
+        iq = synth_channel(21 + M, M, S, 1 << 14).copy()
         iq[2 * 7000] = np.float32("nan")
         iq[2 * 9001 + 1] = np.float32("inf")
         iq[2 * 12000] = -np.float32("inf")
-        props = dict(samplesPerBaud=8, constelationSize=M, numAvg=100, differentialDecoding=diff)
+        props = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, differentialDecoding=diff)
         ref = oracle_run(oracle_mod, iq, props, packet=4096)
         h = _handle()
         h.configure(0, [props])
-        got = run_gpu(h, 0, iq, 0.01, 4096)
-        assert_parity(got, ref, "non-finite M%d diff%d" % (M, diff))
+        n = iq.size // 2
+        outs = {"soft": [], "bits": [], "phase": [], "index": []}
+        seq_calls = 0
+        for k, pos in enumerate(range(0, n, 4096)):
+            r = h.process_host(0, [dict(data=iq[2 * pos : 2 * min(pos + 4096, n)], xdelta=0.01, sriChanged=(k == 0))])[0]
+            for key in outs:
+                outs[key].append(r[key])
+            seq_calls += h.stats()["channels_sequential"]
+        got = {k: np.concatenate(v) for k, v in outs.items()}
+        assert_parity(got, ref, "non-finite M%d diff%d S%d A%d" % (M, diff, S, A))
+        assert seq_calls == 0, seq_calls
+        assert not np.isfinite(ref["soft"]).all()  # (the case is what it claims to be)
         h.close()
+
+
+def test_one_poisoned_channel_does_not_hold_up_the_batch(oracle_mod):
+    """256 channels, one of them fed a NaN sample in the first call.  The reference's state never recovers from
+    that (its phase estimate is NaN or astronomically large from then on), and neither does the channel here: every
+    later call of it goes through the exact-timing tier.  What must not happen is what round 1 did -- the whole
+    batch waiting 150 ms per call for that one channel on the reference-order kernel.  Compared: the same batch
+    with and without the poison, timed over the same calls."""
+    import time
+
+    from psk_soft_amd.stimulus import synth_channel
+
+    C, S, M, N, calls = 256, 8, 4, 32768, 6
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100)
+    base = [synth_channel(4000 + c, M, S, N * calls) for c in range(C)]
+    sick = 77
+
+    def run(poison):
+        chans = [x for x in base]
+        if poison:
+            chans[sick] = base[sick].copy()
+            chans[sick][2 * 5000] = np.float32("nan")
+        h = _handle(C)
+        h.configure(0, [props] * C)
+        res_last, t_calls = None, []
+        for k in range(calls):
+            pk = [dict(data=x[2 * k * N : 2 * (k + 1) * N], xdelta=0.01, sriChanged=(k == 0)) for x in chans]
+            t0 = time.perf_counter()
+            res_last = h.process_host(0, pk)
+            t_calls.append(time.perf_counter() - t0)
+            st = h.stats()
+            assert st["channels_sequential"] == 0, (k, st)
+        h.close()
+        return res_last, t_calls, chans
+
+    clean, t_clean, _ = run(False)
+    dirty, t_dirty, chans = run(True)
+    # the healthy channels: same bits with and without the neighbour's poison (spot check against the oracle too)
+    for c in (0, sick - 1, sick + 1, C - 1):
+        for key in ("soft", "phase", "bits", "index"):
+            assert np.array_equal(clean[c][key].view(np.uint8), dirty[c][key].view(np.uint8)), (c, key)
+    o = oracle_mod.OracleComponent()
+    o.samplesPerBaud, o.constelationSize, o.numAvg = S, M, 100
+    r = None
+    for k in range(calls):
+        r = o.service(chans[sick][2 * k * N : 2 * (k + 1) * N], 0.01, sriChanged=(k == 0))
+    assert_parity(dirty[sick], dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "the poisoned channel, last call")
+    # steady-state calls (the first one of each run warms things up): the poisoned batch within 25 % of the clean one
+    # (host-buffer path: copies dominate; the reference-order kernel would add 150 ms to each)
+    a, b = sorted(t_clean[1:])[len(t_clean[1:]) // 2], sorted(t_dirty[1:])[len(t_dirty[1:]) // 2]
+    assert b < 1.25 * a + 0.004, (t_clean, t_dirty)
 
 
 def test_noisy_unwrap_fixed_point(oracle_mod):
