@@ -25,11 +25,19 @@
 //                  some symbol fails that test is redone exactly on the spot from the LDS ring
 //                  (numAvg <= 128); for larger windows the wave refuses the call (nothing
 //                  committed) and the EXACT = true kernel, launched right behind it, redoes it.
-//                  For numAvg <= 128 there is no EXACT = true instantiation at all.
+//                  What this tier does not carry at all -- a sample that is inf or NaN, an M-th power
+//                  that overflows -- it hands over the same way (every window class has both
+//                  instantiations), stopping at the block where it notices.
 //   EXACT = true   the sums are float-valued addends accumulated in double: exact, hence equal
 //                  to the reference's whatever the summation order (quirk Q8), under the
 //                  exponent-spread guard; near-ties resolve by std::max_element's first-maximum
-//                  rule exactly as the reference's do.
+//                  rule exactly as the reference's do.  The sums are updated symbol by symbol like
+//                  the reference's, so an inf or NaN energy takes them through the same values (inf
+//                  while the sample is in the window, NaN from the moment it leaves to the end of the
+//                  call); this tier also carries libgcc's complex-multiply recovery (cmul<true>) and
+//                  64-bit unwrap counts: calls with non-finite samples, or with the NaN / astronomically
+//                  large phase estimate such a sample leaves behind in the channel, finish here at the
+//                  wave-scan kernels' speed (the reference has no special case for them either).
 #ifndef PSK_FAST_LOOP_H
 #define PSK_FAST_LOOP_H
 

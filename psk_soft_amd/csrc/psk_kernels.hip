@@ -18,7 +18,8 @@
 //       output   (cpp/psk_soft.cpp:484-566)  de-rotation, hard bits, 4 output streams.
 //   psk_seq_kernel    the reference-order kernel (this file): lane 0 replays the reference's
 //       statement order exactly (any property values, samplesPerBaud == 1, calls longer than
-//       2^20 symbols, and every call both wave-scan kernels refused).
+//       2^20 symbols, and every call both wave-scan kernels refused: energy sums that are not exact with an
+//       argmax too close to call, an unwrap that does not settle).
 //
 // Built with -ffp-contract=off (quirk Q9).  No MFMA: the path is a streaming complex-MAC
 // with O(1) flop/byte, bound by HBM.
@@ -312,9 +313,8 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
 namespace psk {
 #define PSK_DECL(S, H, E) hipError_t launch_fast_S##S##_H##H##_E##E(PSK_FAST_ARGS);
 #define PSK_DECL_SH(S, H) PSK_DECL(S, H, 0) PSK_DECL(S, H, 1)
-// (numAvg <= 128 has no exact-timing instantiation: its screened kernel settles near-ties itself, and
-// whatever else makes it refuse a call -- non-finite data, the exactness guard -- the exact kernel
-// would refuse too; those calls go straight to the reference-order kernel)
+// (numAvg <= 128: the screened kernel settles near-ties itself; its exact-timing sibling takes the calls with
+// non-finite samples or a non-finite / astronomically large phase estimate in the channel state)
 #define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
 PSK_DECL_S(2)
 PSK_DECL_S(3)
