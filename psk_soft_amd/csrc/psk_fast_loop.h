@@ -393,6 +393,11 @@ PSK_DEV void refine_unwrap(int lane, uint32_t n, float est_prev0, const float (&
 // ---------------------------------------------------------------------------------------------
 PSK_DEV double pow2_biased(int eb) { return __hiloint2double((int)((unsigned)eb << 20), 0); }
 PSK_DEV bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+// wave votes straight from the lane mask of a condition (HIP's __ballot / __any / __all take an int: the compiler
+// then turns the mask into 0 / 1 per lane and back)
+PSK_DEV unsigned long long vote_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+PSK_DEV bool vote_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+PSK_DEV bool vote_all(bool b) { return __builtin_amdgcn_ballot_w64(!b) == 0ull; }
 PSK_DEV bool odd_f64(double n) { return __builtin_amdgcn_fract(n * 0.5) != 0.0; }  // n integer-valued
 
 // xySum candidates for the 128 positions of a block, in the reference's order of roundings.
@@ -446,9 +451,9 @@ PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const doubl
     // parity entering this lane: the lane's two positions composed, then segmented over the wave
     const bool Ac = T[0] || T[1];
     const bool Vc = T[1] ? V[1] : (V[0] != V[1]);
-    const unsigned long long mA = __ballot(Ac), mV = __ballot(Vc);
+    const unsigned long long mA = vote_mask(Ac), mV = vote_mask(Vc);
     const bool G = (__builtin_amdgcn_mbcnt_hi((unsigned)(mV >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mV, 0u)) & 1u) != 0;
-    const unsigned long long mF = __ballot(Ac && G);
+    const unsigned long long mF = vote_mask(Ac && G);
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     const unsigned long long X = mA & lt, Y = mF & lt;  // ties below this lane; ... those whose G is odd
     const bool P_c = modeB ? odd_f64(S_c * 0.5) : odd_f64(S_c);
@@ -489,8 +494,8 @@ PSK_DEV int fit_sums_verify(const bool (&valid)[kR], const bool (&steady)[kR], f
     float t1 = y[1] * sizef[1];
     t1 = t1 * xd;
     const bool x0 = (xs_prev - c0) + (double)t0 == xySum_l[0], x1 = (xySum_l[0] - c1) + (double)t1 == xySum_l[1];
-    const bool y_ok = __all((y0 || !valid[0]) && (y1 || !valid[1]));
-    const bool x_ok = __all((x0 || !valid[0]) && (x1 || !valid[1]));
+    const bool y_ok = vote_all((y0 || !valid[0]) && (y1 || !valid[1]));
+    const bool x_ok = vote_all((x0 || !valid[0]) && (x1 || !valid[1]));
     return (y_ok ? 0 : 1) | (x_ok ? 0 : 2);
 }
 
