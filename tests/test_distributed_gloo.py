@@ -67,13 +67,14 @@ def test_two_ranks_shard_channels():
     assert all(o[4] == n_sym for o in out) and n_sym > 0
 
 
-def _run_bench(args, env_extra, timeout=300):
+def _run_bench(args, env_extra, timeout=300, keep_world=False):
     import json
     import subprocess
 
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
+    env.update(env_extra)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, timeout=timeout)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
@@ -113,3 +114,19 @@ def test_bench_two_ranks_share_the_gpu():
                     "--no-cpu-baseline"], {"PSK_BENCH_BACKEND": "gloo", "PSK_BENCH_SHARE_GPU": "1"}, timeout=600)
     assert r["n_gpus"] == 2 and r["check"]["bits_index_exact"] and r["check"]["soft_max_rel_err"] == 0.0
     assert r["config"]["channels_per_gpu"] == 256
+
+
+@pytest.mark.gpu
+def test_bench_rank_through_rccl():
+    """One rank through the calls an N-GPU run makes on RCCL (`init_process_group("nccl")`, barrier, the max and sum
+    reductions on device tensors): the test box has one GPU, so the multi-GPU launch itself is the driver's to run."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run_bench(["--steps", "3", "--warmup", "2", "--channels", "256", "--nsamp", "16384", "--no-cpu-baseline"],
+                   {"PSK_BENCH_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600, keep_world=True)
+    assert r["n_gpus"] == 1 and r["check"]["soft_phase_bit_identical"]
