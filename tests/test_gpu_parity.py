@@ -1051,3 +1051,29 @@ def test_machine_filling_batch_8psk_s10(oracle_mod):
     not a multiple of 10 samples (the symbol clock carries the leftovers from call to call)."""
     C = 4096
     _device_batch(oracle_mod, 8, 10, 100, 50, C, [8197, 8191], sorted(set(range(0, C, 32)) | {C - 1}))
+
+
+def test_round1_one_ulp_case_is_bit_identical_now(oracle_mod):
+    """The case that showed round 1's known deviation (tools/fuzz_gpu.py seed 702, round 0, channel 69; the signal is
+    tests/golden/cases/s13_a64_large_estimate.npy, made by that tool's generator): samplesPerBaud 13, QPSK, numAvg 64,
+    phaseAvg 128, ONE call of 156000 samples in which the phase estimate runs to -1342 rad.  Round 1's kernel, which
+    summed LinearFit's xySum in tree order, put out one phase value one ulp off (symbol 10452: -1175.06396 against
+    -1175.06384) and the soft symbol with it, 1.08e-5 relative -- above the 1e-5 bar.  Every float must have the
+    oracle's bits."""
+    import os
+
+    sig = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases", "s13_a64_large_estimate.npy"))
+    props = dict(samplesPerBaud=13, constelationSize=4, numAvg=64, phaseAvg=128, differentialDecoding=0)
+    o = oracle_mod.OracleComponent()
+    for k, v in props.items():
+        setattr(o, k, v)
+    r = o.service(sig, 0.01, sriChanged=True)
+    assert r.phase.size == 11937 and float(np.abs(r.phase).max()) > 1300.0
+    h = _handle(1)
+    h.configure(0, [props])
+    g = h.process_host(0, [dict(data=sig, xdelta=0.01, sriChanged=True)])[0]
+    st = h.stats()
+    h.close()
+    assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
+    assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "seed 702 / round 0 / channel 69")
+    assert g["phase"].view(np.uint32)[10452] == r.phase.view(np.uint32)[10452]
