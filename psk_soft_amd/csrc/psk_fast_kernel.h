@@ -21,8 +21,11 @@ PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : 
 // Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
 // (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
 // runs on 1 and leaves 2.
+#ifndef PSK_WAVES_PER_SIMD
+#define PSK_WAVES_PER_SIMD 4
+#endif
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? 4 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)
