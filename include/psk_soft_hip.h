@@ -124,6 +124,8 @@ typedef struct psk_soft_stats {
     uint64_t fit_chain_blocks;    /* of those: blocks whose LinearFit sums were redone in the reference's
                                      order of additions by the lane-after-lane chain (the wave-parallel
                                      candidates did not verify: sums crossing a binade or zero)          */
+    uint64_t channels_tiled;      /* of channels_fast: calls carried by the time-tiled kernels (few channels,
+                                     long packets: the call is cut along time, see PSK_SOFT_OPT_TIME_TILED) */
 } psk_soft_stats_t;
 
 uint32_t psk_soft_abi_version(void);
@@ -175,7 +177,13 @@ enum {
     /* 1 (default): a batch that mixes window classes (samplesPerBaud, numAvg <= 128 / 256 / 512 / 1024) launches its
      * classes side by side on streams of the handle, forked off and joined back into the caller's stream; 0: one
      * after the other on the caller's stream.  No effect on results. */
-    PSK_SOFT_OPT_CONCURRENT_CLASSES = 2
+    PSK_SOFT_OPT_CONCURRENT_CLASSES = 2,
+    /* Calls of few channels and many symbols are cut along time (tiles of a few hundred symbols spread over the
+     * machine, one wave per channel left for the feedback unwrap and fit): 1 (default) = where it pays (a window class
+     * of the call with at most 512 channels and at least 2048 symbols out per channel, numAvg <= 128,
+     * samplesPerBaud 2 .. 16), 0 = never, 2 = wherever the kernels exist (tests).  No effect on results.
+     * The environment variable PSK_SOFT_TIME_TILED (0 / 1 / 2) sets the default of new handles. */
+    PSK_SOFT_OPT_TIME_TILED = 3
 };
 psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value);
 

@@ -31,6 +31,16 @@ hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, const uin
 hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipStream_t stream);
+// time-tiled kernels (psk_tile.hip)
+bool tile_front_has(int S, int H);
+hipError_t launch_tile_front(int S, int H, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+                             const ChanState *states, const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw,
+                             float2 *t_s, hipStream_t stream);
+hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+                           uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
+                           const float2 *t_s, float *t_est, hipStream_t stream);
+hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream);
 }  // namespace psk
 
 namespace {
@@ -149,6 +159,9 @@ struct PlanSummary {
     // ring of r_len positions (even, >= numAvg + 128)
     uint32_t max_n[33][9] = {}, max_A[33][9] = {};
     uint32_t max_n_quiet = 0;  // ... and of the channels that emit nothing this call
+    // time-tiled kernels: 128-symbol blocks of the class, in all and of its longest call
+    uint64_t blocks_SH[33][9] = {};
+    uint32_t max_blocks_SH[33][9] = {};
 };
 
 // One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
@@ -174,6 +187,10 @@ inline size_t region_sidx(size_t in_cap) { return in_cap + in_cap + in_cap / 2 +
 inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap + in_cap / 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
+// time-tiled kernels, automatic choice: a class of at most this many channels whose longest call has at least this many
+// 128-symbol blocks; tiles of 2 .. 16 blocks, as many as make this number of tiles
+constexpr uint32_t kTiledMaxChannels = 512, kTiledMinBlocks = 16;
+constexpr uint64_t kTiledTargetTiles = 4096;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                       18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
@@ -207,6 +224,16 @@ struct psk_soft_handle {
     // what the call that last used each plan slot worked on, and on which stream (its end is the slot's event)
     hipStream_t slot_stream[kPlanSlots] = {};
     uint32_t slot_ch0[kPlanSlots] = {}, slot_nch[kPlanSlots] = {};
+    // time-tiled kernels (psk_tile_kernel.h): scratch of one call -- per-tile reports, and per symbol the raw phase, the
+    // picked sample and the phase estimate -- grown on demand; calls that use it on different streams are ordered by tile_ev
+    int opt_tiled = 1;  // PSK_SOFT_OPT_TIME_TILED
+    psk::TileInfo *d_tiles = nullptr;
+    float *d_traw = nullptr, *d_test = nullptr;
+    float2 *d_ts = nullptr;
+    size_t tile_cap = 0, tile_sym_cap = 0;
+    hipEvent_t tile_ev = nullptr;
+    hipStream_t tile_stream = nullptr;  // stream of the last call that used the scratch
+    bool tile_ev_used = false;
     bool poisoned = false;  // a HIP call failed after kernels of a call were enqueued: host mirror and device state may disagree
     // ingest pipeline of the host-buffer entry point (psk_soft_process_host)
     StageSlot stage[kStageSlots];
@@ -247,6 +274,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->last_mode.assign(n_channels, psk::PLAN_SKIP);
     h->device = device;
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
+    if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
+        h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (!h->dry) {
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
@@ -319,6 +348,11 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
         if (h->d_state) (void)hipFree(h->d_state);
         if (h->d_ring) (void)hipFree(h->d_ring);
         if (h->d_yv) (void)hipFree(h->d_yv);
+        if (h->d_tiles) (void)hipFree(h->d_tiles);
+        if (h->d_traw) (void)hipFree(h->d_traw);
+        if (h->d_test) (void)hipFree(h->d_test);
+        if (h->d_ts) (void)hipFree(h->d_ts);
+        if (h->tile_ev) (void)hipEventDestroy(h->tile_ev);
         for (auto &sl : h->stage) {
             if (sl.stream) (void)hipStreamSynchronize(sl.stream);
             if (sl.h_buf) (void)hipHostFree(sl.h_buf);
@@ -441,6 +475,9 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                     r.cnt_SH[p.S][Hh]++;
                     if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
                     if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
+                    const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
+                    r.blocks_SH[p.S][Hh] += nb;
+                    if (nb > r.max_blocks_SH[p.S][Hh]) r.max_blocks_SH[p.S][Hh] = nb;
                 } else {
                     r.any_quiet = true;
                     r.cnt_quiet++;
@@ -518,6 +555,58 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             }
         }
     }
+    // Window classes of few channels and long calls go through the time-tiled kernels first (psk_tile_kernel.h): their
+    // channels get a place in the scratch of the call -- symbols padded to whole blocks, K blocks to a tile, K chosen so
+    // that the class makes a few thousand tiles.
+    bool tiled_SH[33][9] = {};
+    uint32_t tiles_max_SH[33][9] = {};
+    size_t tile_syms = 0, tile_count = 0;
+    if (h->opt_tiled) {
+        for (int S : kFastS)
+            for (int H = 1; H <= 8; H <<= 1) {
+                if (!res.need_SH[S][H] || !psk::tile_front_has(S, H))
+                    continue;
+                if (h->opt_tiled == 1 && !(res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks))
+                    continue;
+                uint64_t K = res.blocks_SH[S][H] / kTiledTargetTiles;
+                K = K < 2 ? 2 : K > 16 ? 16 : K;
+                tiled_SH[S][H] = true;
+                tiles_max_SH[S][H] = (uint32_t)((res.max_blocks_SH[S][H] + K - 1) / K);
+                for (uint32_t i = 0; i < res.cnt_SH[S][H]; i++) {
+                    psk::ChanPlan &p = plans[h_list[off_SH[S][H] + i]];
+                    const uint64_t nb = (p.n_out + 127u) / 128u;
+                    p.lf_flags |= psk::PLAN_TILED;
+                    p.tile_blocks = (uint32_t)K;
+                    p.tile_base = (uint32_t)tile_count;
+                    p.tile_off = tile_syms;
+                    tile_count += (size_t)((nb + K - 1) / K);
+                    tile_syms += (size_t)nb * 128u;
+                }
+            }
+    }
+    if (tile_syms) {
+        if (tile_syms > h->tile_sym_cap || tile_count > h->tile_cap) {
+            // (rare: the scratch grows to the largest call seen, plus a quarter)
+            PSK_HIP(hipDeviceSynchronize());
+            if (h->d_tiles) (void)hipFree(h->d_tiles);
+            if (h->d_traw) (void)hipFree(h->d_traw);
+            if (h->d_test) (void)hipFree(h->d_test);
+            if (h->d_ts) (void)hipFree(h->d_ts);
+            h->d_tiles = nullptr, h->d_traw = h->d_test = nullptr, h->d_ts = nullptr;
+            h->tile_cap = h->tile_sym_cap = 0;
+            const size_t syms = tile_syms + tile_syms / 4, cnt = tile_count + tile_count / 4;
+            PSK_HIP(hipMalloc((void **)&h->d_tiles, sizeof(psk::TileInfo) * cnt));
+            PSK_HIP(hipMalloc((void **)&h->d_traw, sizeof(float) * syms));
+            PSK_HIP(hipMalloc((void **)&h->d_test, sizeof(float) * syms));
+            PSK_HIP(hipMalloc((void **)&h->d_ts, sizeof(float2) * syms));
+            h->tile_cap = cnt;
+            h->tile_sym_cap = syms;
+        }
+        if (!h->tile_ev)
+            PSK_HIP(hipEventCreateWithFlags(&h->tile_ev, hipEventDisableTiming));
+        if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
+            PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
+    }
     PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
                            hipMemcpyHostToDevice, stream));
     // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
@@ -573,6 +662,15 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             }
             const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
             const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
+            if (tiled_SH[S][H]) {
+                // (a call these cannot carry comes out with guard 1 and nothing committed: the launches below redo it)
+                PSK_HIP(psk::launch_tile_front(S, H, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
+                                               h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts, st));
+                PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring,
+                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, st));
+                PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
+                                              h->d_tiles, h->d_ts, h->d_test, st));
+            }
             for (int exact = 0; exact <= 1; exact++)  // (the exact tier only works on the calls the screened tier left)
                 PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
@@ -584,6 +682,8 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
             PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                     h->lim.fit_cap, stream));
+        if (tile_syms)
+            PSK_HIP(hipEventRecord(h->tile_ev, stream));
         PSK_HIP(hipEventRecord(h->ev[slot], stream));
         return PSK_SOFT_OK;
     };
@@ -593,6 +693,10 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         return est;
     }
     commit();
+    if (tile_syms) {
+        h->tile_ev_used = true;
+        h->tile_stream = stream;
+    }
     h->slot = (h->slot + 1) % kPlanSlots;
     h->ev_used[slot] = true;
     h->slot_stream[slot] = stream;
@@ -840,6 +944,8 @@ static void stats_add(psk_soft_stats_t *stats, uint32_t mode, const psk::ChanSta
             stats->channels_fast++;
             if (s.guard == 3u)
                 stats->channels_exact_timing++;
+            if (s.guard == 4u)
+                stats->channels_tiled++;
             stats->unwrap_blocks += s.stat_blocks;
             stats->unwrap_extra_passes += s.stat_extra;
             stats->timing_exact_blocks += s.stat_exact;
@@ -891,6 +997,11 @@ psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)
     switch (option) {
     case PSK_SOFT_OPT_QPSK_SIGN_BITMAP: h->opt_qpsk_sign_map = value != 0; return PSK_SOFT_OK;
     case PSK_SOFT_OPT_CONCURRENT_CLASSES: h->opt_fork = value != 0; return PSK_SOFT_OK;
+    case PSK_SOFT_OPT_TIME_TILED:
+        if (value < 0 || value > 2)
+            return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: PSK_SOFT_OPT_TIME_TILED takes 0, 1 or 2");
+        h->opt_tiled = value;
+        return PSK_SOFT_OK;
     default: return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: unknown option");
     }
 }

@@ -10,69 +10,14 @@ namespace psk {
 // number of 128-symbol blocks of window history an instantiation keeps in registers for numAvg = A
 PSK_HD int hist_blocks_for(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : A <= 512u ? 4 : 8; }
 
-// SV = samplesPerBaud this instantiation handles, HV = blocks of window history kept in
-// registers (numAvg <= 128 HV), EXACT = timing by the exact double pass (else the float
-// screening pass, see psk_fast_loop.h).  SV == 0 takes the channels of the batch that emit
-// nothing this call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
-// Register budget: the numAvg <= 128, samplesPerBaud <= 10 instantiations are held to 128 VGPRs
-// (4 waves per SIMD = 16 single-wave workgroups per CU, so a 4096-channel batch is resident at
-// once; samplesPerBaud = 9 and 10 pay for it with a handful of spilled VGPRs and win 20 % by the
-// residency); the others keep what they need.
-// Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
-// (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
-// runs on 1 and leaves 2.
-#ifndef PSK_WAVES_PER_SIMD
-#define PSK_WAVES_PER_SIMD 4
-#endif
-template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                      ChanState *__restrict__ states, float2 *__restrict__ rings,
-                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
-                                                      uint32_t y_len, uint32_t r_len)
+// Per-call prologue of a channel (shared with the time-tiled fit kernel, psk_tile_kernel.h): LinearFit history into
+// the LDS ring, the carried state into `cy`; LinearFit::reset() sums if it ran.
+PSK_DEV void call_prologue(const ChanPlan &p, const ChanState *st, const float *yv, uint32_t fit_cap, float *yring, uint32_t ymask,
+                           int lane, FastCarry &cy)
 {
-    // LDS: a ring of the last unwrapped phases (y_len floats, a power of two >= phaseAvg + 128 for every
-    // channel of the launch, sized by the host: dynamic LDS) and, for numAvg <= 128, the energy ring of
-    // SV rows -- 256 positions each, static, except samplesPerBaud = 9, 10 where the rows follow the
-    // phase ring in the dynamic segment at r_len positions each (see psk_fast_loop.h).
-    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    constexpr bool kDyn = ering_dynamic(SV);
-    float *const yring = lds_dyn;
-    const uint32_t ymask = y_len - 1u;
-    ERingT<kDyn> er;
-    if constexpr (kDyn) {
-        er.mem = lds_dyn + y_len;
-        er.set_len((int)r_len);
-    } else {
-        __shared__ __attribute__((aligned(16))) float ering_s[(SV != 0 && HV == 1) ? SV * kERing : 4];
-        er.mem = ering_s;
-    }
-    const int lane = threadIdx.x & 63;
-    // the launch covers the channels of the batch that this instantiation handles: list[workgroup] = index into the batch
-    const uint32_t bi = list[blockIdx.x];
-    const ChanPlan &p = plans[bi];
-    if (p.mode != PLAN_FAST)
-        return;
-    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV))
-        return;
-    if (EXACT && states[ch0 + bi].guard != 1u)
-        return;  // the screened kernel finished this channel's call
-    const uint32_t ch = ch0 + bi;
-    ChanState *st = &states[ch];
-    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
-    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
-    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
-    float *yv = yvs + (size_t)ch * fit_cap;
-
-    XView X;
-    X.ring = reinterpret_cast<const f2g *>(ring_src);
-    X.in = reinterpret_cast<const f2g *>(p.in);
-    X.L0 = p.ring_len0;
-
-    // ---- prologue: LinearFit history into the LDS ring; LinearFit::reset() sums if it ran ----
-    const uint32_t len0 = p.lf_len0, n = p.lf_n;
+    const uint32_t len0 = p.lf_len0;
     for (uint32_t j = lane; j < len0; j += kWave) yring[j & ymask] = yv[(p.lf_head + j) % fit_cap];
     wave_lds_fence();
-    FastCarry cy;
     cy.ySum = st->lf_ySum;
     cy.xySum = st->lf_xySum;
     cy.est = st->phaseEstimate;
@@ -104,35 +49,15 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
             cy.b = len0 ? yring[(len0 - 1) & ymask] : 0.0f;
         }
     }
+}
 
-    // ---- the symbol loop ----
-    if constexpr (SV != 0)
-        fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy);
-
-    // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
-    //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
-    //      for calls in which an exact-timing pass met a best / runner-up pair closer than accumulated
-    //      rounding could explain (cy.ambiguous, psk_fast_loop.h): everywhere else the argmax is the
-    //      reference's whether or not the sums are exact ----
-    {
-        unsigned umax = wave_max_u32(cy.umax);
-        unsigned umin1 = wave_min_u32(cy.umin1);
-        if (umin1 != 0xFFFFFFFFu && __any(cy.ambiguous)) {
-            int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
-            emax = emax < 1 ? 1 : emax;
-            emin = emin < 1 ? 1 : emin;
-            int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
-            if (24 + (emax - emin) + terms_log2 > 52)
-                cy.refuse = true;
-        }
-        cy.refuse = __any(cy.refuse);
-    }
-    if (cy.refuse) {
-        if (lane == 0)
-            st->guard = 1u;  // nothing committed: psk_seq_kernel redoes this call from the old state
-        return;
-    }
-
+// End of a call that ran to completion (shared with the time-tiled fit kernel): end-of-call wrap, then the channel
+// state is committed -- LinearFit history and sums, the surviving samples into the other ring buffer, `guard_done` into
+// ChanState::guard.
+PSK_DEV void call_epilogue(const ChanPlan &p, ChanState *st, float *yv, uint32_t fit_cap, float *yring, uint32_t ymask, const XView &X,
+                           float2 *ring_dst, int lane, FastCarry &cy, uint32_t guard_done)
+{
+    const uint32_t len0 = p.lf_len0, n = p.lf_n;
     // ---- end-of-call wrap (cpp/psk_soft.cpp:592-603) ----
     const uint32_t grown = len0 + (uint32_t)p.n_out;  // n_out <= 2^20 on this path
     const uint32_t len1 = grown < n ? grown : n;
@@ -178,7 +103,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
             st->lf_den = cy.den;
             st->lf_xavg = cy.xavg;
             st->lf_m = cy.slope;
-            st->guard = EXACT ? 3u : 0u;
+            st->guard = guard_done;
             st->last_k = cy.last_k;
             st->stat_blocks = cy.stat_blocks;
             st->stat_extra = cy.stat_extra;
@@ -186,6 +111,101 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
             st->stat_chain = cy.stat_chain;
         }
     }
+}
+
+// SV = samplesPerBaud this instantiation handles, HV = blocks of window history kept in
+// registers (numAvg <= 128 HV), EXACT = timing by the exact double pass (else the float
+// screening pass, see psk_fast_loop.h).  SV == 0 takes the channels of the batch that emit
+// nothing this call (warm-up, stalled window) whatever their samplesPerBaud / numAvg.
+// Register budget: the numAvg <= 128, samplesPerBaud <= 10 instantiations are held to 128 VGPRs
+// (4 waves per SIMD = 16 single-wave workgroups per CU, so a 4096-channel batch is resident at
+// once; samplesPerBaud = 9 and 10 pay for it with a handful of spilled VGPRs and win 20 % by the
+// residency); the others keep what they need.
+// Hand-over protocol through ChanState::guard: the screened kernel leaves 0 (done) or 1
+// (refused); the exact kernel runs on 1 and leaves 3 (done) or 1; the reference-order kernel
+// runs on 1 and leaves 2.  A call planned for the time-tiled kernels (PLAN_TILED) starts there: they
+// leave 4 (done) or 1, and the screened kernel runs on 1 only.
+#ifndef PSK_WAVES_PER_SIMD
+#define PSK_WAVES_PER_SIMD 4
+#endif
+template <int SV, int HV, bool EXACT>
+__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                      ChanState *__restrict__ states, float2 *__restrict__ rings,
+                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
+                                                      uint32_t y_len, uint32_t r_len)
+{
+    // LDS: a ring of the last unwrapped phases (y_len floats, a power of two >= phaseAvg + 128 for every
+    // channel of the launch, sized by the host: dynamic LDS) and, for numAvg <= 128, the energy ring of
+    // SV rows -- 256 positions each, static, except samplesPerBaud = 9, 10 where the rows follow the
+    // phase ring in the dynamic segment at r_len positions each (see psk_fast_loop.h).
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    constexpr bool kDyn = ering_dynamic(SV);
+    float *const yring = lds_dyn;
+    const uint32_t ymask = y_len - 1u;
+    ERingT<kDyn> er;
+    if constexpr (kDyn) {
+        er.mem = lds_dyn + y_len;
+        er.set_len((int)r_len);
+    } else {
+        __shared__ __attribute__((aligned(16))) float ering_s[(SV != 0 && HV == 1) ? SV * kERing : 4];
+        er.mem = ering_s;
+    }
+    const int lane = threadIdx.x & 63;
+    // the launch covers the channels of the batch that this instantiation handles: list[workgroup] = index into the batch
+    const uint32_t bi = list[blockIdx.x];
+    const ChanPlan &p = plans[bi];
+    if (p.mode != PLAN_FAST)
+        return;
+    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV))
+        return;
+    if (EXACT && states[ch0 + bi].guard != 1u)
+        return;  // the screened kernel finished this channel's call
+    if (!EXACT && SV != 0 && (p.lf_flags & PLAN_TILED) && states[ch0 + bi].guard != 1u)
+        return;  // ... or the time-tiled kernels did, launched in front of this one (psk_tile_kernel.h)
+    const uint32_t ch = ch0 + bi;
+    ChanState *st = &states[ch];
+    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
+    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
+    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
+    float *yv = yvs + (size_t)ch * fit_cap;
+
+    XView X;
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
+    X.L0 = p.ring_len0;
+
+    FastCarry cy;
+    call_prologue(p, st, yv, fit_cap, yring, ymask, lane, cy);
+
+    // ---- the symbol loop ----
+    if constexpr (SV != 0)
+        fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy);
+
+    // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
+    //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
+    //      for calls in which an exact-timing pass met a best / runner-up pair closer than accumulated
+    //      rounding could explain (cy.ambiguous, psk_fast_loop.h): everywhere else the argmax is the
+    //      reference's whether or not the sums are exact ----
+    {
+        unsigned umax = wave_max_u32(cy.umax);
+        unsigned umin1 = wave_min_u32(cy.umin1);
+        if (umin1 != 0xFFFFFFFFu && __any(cy.ambiguous)) {
+            int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
+            emax = emax < 1 ? 1 : emax;
+            emin = emin < 1 ? 1 : emin;
+            int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
+            if (24 + (emax - emin) + terms_log2 > 52)
+                cy.refuse = true;
+        }
+        cy.refuse = __any(cy.refuse);
+    }
+    if (cy.refuse) {
+        if (lane == 0)
+            st->guard = 1u;  // nothing committed: psk_seq_kernel redoes this call from the old state
+        return;
+    }
+
+    call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, EXACT ? 3u : 0u);
 }
 
 #define PSK_FAST_ARGS                                                                                          \

@@ -69,6 +69,10 @@ struct FastCarry {
     uint32_t stat_chain;   // blocks whose LinearFit sums went through the reference-order chain (fit_sums_chain)
     uint32_t chain_run;    // > 0: the chain ran on several blocks in a row -- the next blocks go straight to it (see fast_main_loop)
     uint32_t chain_streak; // low half: chained blocks in a row; high half: blocks left of the raised priority
+    float gap_rel;         // (time-tiled front kernel only) smallest gap / relative bound among the exact re-decisions: a tile
+                           // does not know the largest sum of the whole call, the fit kernel compares once it does
+    float cap;             // (time-tiled front kernel only) largest window sum anywhere in the call up to which the screening
+                           // thresholds this tile used still exceed what the reference's running sums may have drifted by
 };
 
 // exactness guard bookkeeping: max of the energy bit patterns and min of (bits - 1); a zero
@@ -802,10 +806,10 @@ PSK_DEV bool argtop_ambiguous(const ArgTop &t, float bound_abs)
 // within its error bound -- is not below best - thr at every failing position (thr covers twice the
 // bound, see the screening pass).  On a shaped pulse two phases contend, so a redo costs two double scans
 // and S - 2 float ones instead of S double ones.  (A NaN compares false: such a phase stays in.)
-template <int S>
+template <int S, bool FRONT = false>
 PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base, uint32_t A, int lane, FastCarry &cy, int (&bestK)[kR],
                                    float bound_abs, const bool (&fail)[kR], const float (&best_f)[kR],
-                                   const int (&second_k)[kR], float thr)
+                                   const int (&second_k)[kR], float thr, float bound_rel = 1.0f)
 {
     const int i_new = er.wrap(base + 2 * lane);
     const int i_prev = er.wrap(base - kB + 2 * lane);
@@ -870,12 +874,220 @@ PSK_DEV void exact_block_from_ring(const ERingT<ering_dynamic(S)> &er, int base,
         if (fail[r]) {
             bestK[r] = top[r].k;
             cy.ambiguous = cy.ambiguous || argtop_ambiguous(top[r], bound_abs);
+            if constexpr (FRONT) {
+                const float g = top[r].gap / bound_rel;
+                cy.gap_rel = (g < cy.gap_rel) ? g : ((g == g) ? cy.gap_rel : 0.0f);  // (NaN: ambiguous whatever the scale)
+            }
         }
     }
 }
 
-template <int S, int H, bool EXACT>
-PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uint32_t ymask, const ERingT<ering_dynamic(S)> &er, FastCarry &cy)
+// Feedback unwrap + LinearFit::next over one block of 128 symbols (reference cpp/psk_soft.cpp:476-481, 48-87): the
+// raw phases in, the phase estimates out, the carried sums / estimate / window bookkeeping of `cy` advanced to the
+// block's last valid position.  `c` = index of the block in the call.
+template <bool EXACT>
+PSK_DEV void fit_stage(int c, int lane, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk, const bool (&valid)[kR],
+                       const float (&raw)[kR], int nvalid, int lane_last, int r_last, float *yring, uint32_t ymask, FastCarry &cy,
+                       float (&est)[kR])
+{
+    const uint32_t q0 = cy.q;
+    float y[kR];
+    double ySum_l[kR], xySum_l[kR];
+    float den_last = den_s, xavg_last = xavg_s;
+    int pass, rejected = 0;
+    const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
+    const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
+    if (!warm) {
+        pass = fit_block<false, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+                                lane_last, r_last, den_last, xavg_last, cheap, rejected);
+    } else {
+        pass = fit_block<true, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
+                               lane_last, r_last, den_last, xavg_last, cheap, rejected);
+    }
+#ifdef PSK_ABL_NOCHAIN  /* (ablation builds only: what the chain costs) */
+    rejected = 0;
+#endif
+    if (rejected) {
+        // The candidates are not the reference's sums (or were not attempted): the recurrence itself, then the
+        // estimates from ITS sums.  The unwrap counts were verified against the candidates' estimates, which
+        // differ from these by an ulp here and there: a count that would change under them (a feedback within
+        // an ulp of the half-way point of the unwrap) sends the call to the reference-order kernel.
+        if (!warm)
+            fit_sums_chain<false>((rejected & 1) != 0, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
+        else
+            fit_sums_chain<true>(true, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
+        float est2[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            float m_, b_;
+            if (!warm) {
+                est2[r] = fit_value_known(ySum_l[r], xySum_l[r], fk, m_);
+            } else {
+                const uint32_t before = q0 + (uint32_t)(2 * lane + r);
+                const uint32_t pts = before < n ? before + 1 : n;
+                float den_r = den_s, xavg_r = xavg_s;
+                if (pts > 1 && pts < n)
+                    fit_denominator(xd, pts, den_r, xavg_r);
+                est2[r] = pts > 1 ? fit_value(ySum_l[r], xySum_l[r], xd, pts, den_r, xavg_r, m_, b_) : y[r];
+            }
+        }
+        const float fb0 = wave_up1(est2[1], cy.est), old_fb0 = wave_up1(est[1], cy.est);
+        const bool diff0 = valid[0] && __float_as_uint(fb0) != __float_as_uint(old_fb0);
+        const bool diff1 = valid[1] && __float_as_uint(est2[0]) != __float_as_uint(est[0]);
+        if (__any(diff0 || diff1)) {  // (an ulp here and there: does any count see it?)
+            const bool moved0 = diff0 && unwrap_count(fb0, (double)raw[0], c) != unwrap_count(old_fb0, (double)raw[0], c);
+            const bool moved1 = diff1 && unwrap_count(est2[0], (double)raw[1], c) != unwrap_count(est[0], (double)raw[1], c);
+            if (__any(moved0 || moved1))
+                cy.refuse = true;
+        }
+        est[0] = est2[0];
+        est[1] = est2[1];
+        cy.stat_chain += 1;
+        // a block whose candidates failed is usually followed by more of them (sums wandering around zero):
+        // the next few blocks go straight to the recurrence, then the candidates get another try
+        if (cheap)
+            cy.chain_run -= 1;
+        else if (!warm)
+            cy.chain_run = (cy.chain_streak & 0xffffu) >= PSK_CHAIN_STREAK ? PSK_CHAIN_RUN : 0;
+        cy.chain_streak = ((cy.chain_streak & 0xffffu) + 1u) | (16u << 16);
+    } else {
+        cy.chain_streak = (cy.chain_streak >> 16) ? ((cy.chain_streak >> 16) - 1u) << 16 : 0u;
+    }
+    if (pass > kMaxUnwrapPasses)
+        cy.refuse = true;
+    cy.stat_blocks += 1;
+    cy.stat_extra += (uint32_t)pass;
+    // ---- carries into the next block: the last valid position of this one ----
+    {
+        const double ys = r_last ? ySum_l[1] : ySum_l[0];
+        const double xys = r_last ? xySum_l[1] : xySum_l[0];
+        const float e_ = r_last ? est[1] : est[0];
+        cy.ySum = read_lane(ys, lane_last);
+        cy.xySum = read_lane(xys, lane_last);
+        cy.est = read_lane(e_, lane_last);
+        {
+            // slope of the line just fitted, per symbol (LinearFit::m * xdelta, steady-state
+            // constants): only a hint for the next block's speculation, so approximate is fine
+            float m_hint;
+            (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
+            m_hint *= xd;
+            cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
+        }
+        const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
+        if (pts_last > 1) {  // calculateDenominator ran for the window size reached (cpp/psk_soft.cpp:81-83)
+            cy.den = den_last;
+            cy.xavg = xavg_last;
+        }
+    }
+    cy.q = q0 + (uint32_t)nvalid;
+}
+
+// De-rotation and hard decisions of one block (reference cpp/psk_soft.cpp:484-566) and its soft / phase / bits output,
+// two symbols per lane.  `last_c` = the sample output just before the block's first one (differential decoding);
+// G: the output rows are addressed as global memory (see PSK_GLOBAL), EXACT: libgcc's complex-multiply recovery.
+template <bool G, bool EXACT>
+PSK_DEV void output_stage(const ChanPlan &p, int c, int i0, const bool (&valid)[kR], const cf32 (&s)[kR], const float (&est)[kR],
+                          cf32 last_c, const AtanTabDev &atab, bool qpsk_sign_map, bool m_pow2, float inv_M)
+{
+    const uint32_t M = p.M;
+    cf32 corr[kR];
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+        float phaseCorrection = 0.0f;
+        cf32 smp = s[r];
+        if (p.diff) {
+            cf32 last;
+            if (r == 0) {
+                last.re = wave_up1(s[1].re, last_c.re);
+                last.im = wave_up1(s[1].im, last_c.im);
+            } else {
+                last = s[0];
+            }
+            smp = cdiv<true>(s[r], last);  // (__divsc3's recovery behind a wave-uniform test: a silent
+                                           //  stream divides by zero on every symbol)
+        } else {
+            phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
+        }
+        if (M == 4)
+            phaseCorrection = (float)((double)phaseCorrection + PSK_KD(kPi4, c));
+        float sn, cs;
+        sincosf_wave(phaseCorrection, &sn, &cs, c);
+        cf32 ph;
+        ph.re = 1.0f * cs;
+        ph.im = 1.0f * sn;
+        // (__mulsc3's recovery only ever changes a product with an infinite factor: impossible
+        // without differential decoding, where smp is a sample whose M-th power was finite)
+        corr[r] = (p.diff || EXACT) ? cmul<true>(smp, ph) : cmul<false>(smp, ph);
+    }
+
+    // ---- four output streams, two symbols per lane ----
+    unsigned short sym8[kR] = {0, 0};
+    if (p.bits && p.bpb == 3) {  // 8-PSK slicing with the whole wave active (the atan2f table lives in lanes 0-4)
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            sym8[r] = slice_8psk(corr[r].re, corr[r].im, atab);
+        }
+    }
+    if (valid[1]) {
+        if (p.soft) {
+            f4u v = {corr[0].re, corr[0].im, corr[1].re, corr[1].im};
+            store_f4u(mem_ptr<G>(p.soft) + 2 * (size_t)i0, v);
+        }
+        if (p.phase) {
+            f2u v = {est[0], est[1]};
+            store_f2u(mem_ptr<G>(p.phase) + i0, v);
+        }
+        if (!p.bits) {
+        } else if (p.bpb == 1) {
+            s2u v = {(short)(corr[0].re < 0), (short)(corr[1].re < 0)};
+            store_s2u(mem_ptr<G>(p.bits) + i0, v);
+        } else if (p.bpb == 2) {  // quirk Q1 (float -> bool is "!= 0") unless the sign map was asked for
+            int a0, a1, b0, b1;
+            qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
+            qpsk_bits(corr[1].re, corr[1].im, qpsk_sign_map, b0, b1);
+            s4u v = {(short)a0, (short)a1, (short)b0, (short)b1};
+            store_s4u(mem_ptr<G>(p.bits) + 2 * i0, v);
+        } else if (p.bpb == 3) {
+            const unsigned short a = sym8[0], b = sym8[1];
+            s2u v0 = {(short)(a & 1), (short)((a >> 1) & 1)};
+            s2u v1 = {(short)((a >> 2) & 1), (short)(b & 1)};
+            s2u v2 = {(short)((b >> 1) & 1), (short)((b >> 2) & 1)};
+            store_s2u(mem_ptr<G>(p.bits) + 3 * i0, v0);
+            store_s2u(mem_ptr<G>(p.bits) + 3 * i0 + 2, v1);
+            store_s2u(mem_ptr<G>(p.bits) + 3 * i0 + 4, v2);
+        }
+    } else if (valid[0]) {  // an odd tail: one symbol
+        if (p.soft) {
+            mem_ptr<G>(p.soft)[2 * (size_t)i0] = corr[0].re;
+            mem_ptr<G>(p.soft)[2 * (size_t)i0 + 1] = corr[0].im;
+        }
+        if (p.phase)
+            mem_ptr<G>(p.phase)[i0] = est[0];
+        if (!p.bits) {
+        } else if (p.bpb == 1) {
+            mem_ptr<G>(p.bits)[i0] = (int16_t)(corr[0].re < 0);
+        } else if (p.bpb == 2) {
+            int a0, a1;
+            qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
+            mem_ptr<G>(p.bits)[2 * i0] = (int16_t)a0;
+            mem_ptr<G>(p.bits)[2 * i0 + 1] = (int16_t)a1;
+        } else if (p.bpb == 3) {
+            const unsigned short a = sym8[0];
+            mem_ptr<G>(p.bits)[3 * i0] = (int16_t)(a & 1);
+            mem_ptr<G>(p.bits)[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
+            mem_ptr<G>(p.bits)[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
+        }
+    }
+}
+
+// FRONT = true is the first stage of the time-tiled kernels (psk_tile_kernel.h): the same loop over the blocks
+// [c_begin, c_end) of the call -- its window rebuilt from the numAvg - 1 symbols in front of block c_begin exactly as
+// the call's first window is rebuilt from the carried samples --, stopping after the raw phase: the picked samples
+// and their raw phases go to scratch (t_s, t_raw: the channel's arrays, indexed by output symbol), sampleIndex to
+// the caller.  Unwrap, fit and de-rotation happen in the later stages.
+template <int S, int H, bool EXACT, bool FRONT = false>
+PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uint32_t ymask, const ERingT<ering_dynamic(S)> &er, FastCarry &cy,
+                            int c_begin = 0, int c_end = -1, float *t_raw = nullptr, float2 *t_s = nullptr)
 {
 
     const int lane = threadIdx.x & 63;
@@ -903,7 +1115,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
 #pragma unroll
         for (int h = H - 1; h >= 0; h--) {
             float2 x[kR][S];
-            load_block<S>(X, -(long long)(h + 1), A, 0, (long long)A - 2, lane, x);
+            load_block<S>(X, (long long)c_begin - (long long)(h + 1), A, (long long)c_begin * kB, (long long)c_begin * kB + (long long)A - 2, lane, x);
 #pragma unroll
             for (int r = 0; r < kR; r++) {
 #pragma unroll
@@ -952,7 +1164,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
     const float inv_M = uni(1.0f / (float)(M ? M : 1));
 
-    const int n_blocks = (n_out + kB - 1) / kB;
+    const int n_blocks = (FRONT && c_end >= 0) ? c_end : (n_out + kB - 1) / kB;
     const AtanTabDev atab = atan_tab_dev(lane);  // range table of the straight-line atan2f
     const bool qpsk_sign_map = (p.lf_flags & PLAN_QPSK_SIGN_MAP) != 0;
     int kpred[kR] = {(int)cy.last_k, (int)cy.last_k};  // timing index this lane chose one block ago
@@ -961,7 +1173,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     if constexpr (H == 1)
         ering_put<S>(er, er.length() - kB, lane, hist[0].e);  // block -1
 
-    for (int c = 0; c < n_blocks; c++) {
+    for (int c = c_begin; c < n_blocks; c++) {
         // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
         // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %, touching the next block's
@@ -1087,6 +1299,15 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             // (NaN / inf anywhere makes the comparison false)
             const bool ok0 = !valid[0] || ((__int_as_float(m1[0]) - __int_as_float(m2[0])) > thr);
             const bool ok1 = !valid[1] || ((__int_as_float(m1[1]) - __int_as_float(m2[1])) > thr);
+            if constexpr (FRONT) {
+                // (a position the screening accepts beat its runner-up by more than thr: that decides it against the
+                // reference's sums too while thr >= 2 * drift * (largest sum of the call) -- the single wave of the
+                // wave-scan kernel knows that maximum as it goes, a tile does not)
+                if (__any((valid[0] && ok0) || (valid[1] && ok1))) {
+                    const float cap_blk = thr / (2.0f * drift_bound(c * kB + kB, A));
+                    cy.cap = cap_blk < cy.cap ? cap_blk : cy.cap;
+                }
+            }
             err_c += e_blk;
             wmax_prev = wmax;
             since_refresh++;
@@ -1099,8 +1320,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                     const bool fail[kR] = {!ok0, !ok1};
                     const float best_f[kR] = {__int_as_float(m1[0]), __int_as_float(m1[1])};
                     const int second_k[kR] = {IMASK - (m2[0] & IMASK), IMASK - (m2[1] & IMASK)};
-                    exact_block_from_ring<S>(er, ring_base, A, lane, cy, bestK,
-                                             2.0f * drift_bound(c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr);
+                    exact_block_from_ring<S, FRONT>(er, ring_base, A, lane, cy, bestK,
+                                                    2.0f * drift_bound(c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr,
+                                                    2.0f * drift_bound(c * kB + kB, A));
                     since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
                 } else {
@@ -1201,74 +1423,19 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             raw[r] = atan2f_wave(pw.im, pw.re, atab);
         }
 
+        if constexpr (FRONT) {
+            // (the scratch rows are padded to whole blocks: positions past the end of the call are written too)
+            *reinterpret_cast<float2 *>(t_raw + i0) = make_float2(raw[0], raw[1]);
+            *reinterpret_cast<float4 *>(t_s + i0) = make_float4(s[0].re, s[0].im, s[1].re, s[1].im);
+            cy.stat_blocks += 1;
+            if (__any(cy.refuse)) {  // the whole call goes to the wave-scan kernels
+                cy.refuse = true;
+                return;
+            }
+        } else {
         // ================= feedback unwrap + LinearFit::next, 128 symbols at a time =================
-        const uint32_t q0 = cy.q;
-        float y[kR], est[kR];
-        double ySum_l[kR], xySum_l[kR];
-        float den_last = den_s, xavg_last = xavg_s;
-        int pass, rejected = 0;
-        const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
-        const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
-        if (!warm) {
-            pass = fit_block<false, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                                    lane_last, r_last, den_last, xavg_last, cheap, rejected);
-        } else {
-            pass = fit_block<true, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                                   lane_last, r_last, den_last, xavg_last, cheap, rejected);
-        }
-#ifdef PSK_ABL_NOCHAIN  /* (ablation builds only: what the chain costs) */
-        rejected = 0;
-#endif
-        if (rejected) {
-            // The candidates are not the reference's sums (or were not attempted): the recurrence itself, then the
-            // estimates from ITS sums.  The unwrap counts were verified against the candidates' estimates, which
-            // differ from these by an ulp here and there: a count that would change under them (a feedback within
-            // an ulp of the half-way point of the unwrap) sends the call to the reference-order kernel.
-            if (!warm)
-                fit_sums_chain<false>((rejected & 1) != 0, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
-            else
-                fit_sums_chain<true>(true, lane, lane_last, q0, n, xd, fk.sizef, cy.ySum, cy.xySum, valid, yring, ymask, y, ySum_l, xySum_l);
-            float est2[kR];
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                float m_, b_;
-                if (!warm) {
-                    est2[r] = fit_value_known(ySum_l[r], xySum_l[r], fk, m_);
-                } else {
-                    const uint32_t before = q0 + (uint32_t)(2 * lane + r);
-                    const uint32_t pts = before < n ? before + 1 : n;
-                    float den_r = den_s, xavg_r = xavg_s;
-                    if (pts > 1 && pts < n)
-                        fit_denominator(xd, pts, den_r, xavg_r);
-                    est2[r] = pts > 1 ? fit_value(ySum_l[r], xySum_l[r], xd, pts, den_r, xavg_r, m_, b_) : y[r];
-                }
-            }
-            const float fb0 = wave_up1(est2[1], cy.est), old_fb0 = wave_up1(est[1], cy.est);
-            const bool diff0 = valid[0] && __float_as_uint(fb0) != __float_as_uint(old_fb0);
-            const bool diff1 = valid[1] && __float_as_uint(est2[0]) != __float_as_uint(est[0]);
-            if (__any(diff0 || diff1)) {  // (an ulp here and there: does any count see it?)
-                const bool moved0 = diff0 && unwrap_count(fb0, (double)raw[0], c) != unwrap_count(old_fb0, (double)raw[0], c);
-                const bool moved1 = diff1 && unwrap_count(est2[0], (double)raw[1], c) != unwrap_count(est[0], (double)raw[1], c);
-                if (__any(moved0 || moved1))
-                    cy.refuse = true;
-            }
-            est[0] = est2[0];
-            est[1] = est2[1];
-            cy.stat_chain += 1;
-            // a block whose candidates failed is usually followed by more of them (sums wandering around zero):
-            // the next few blocks go straight to the recurrence, then the candidates get another try
-            if (cheap)
-                cy.chain_run -= 1;
-            else if (!warm)
-                cy.chain_run = (cy.chain_streak & 0xffffu) >= PSK_CHAIN_STREAK ? PSK_CHAIN_RUN : 0;
-            cy.chain_streak = ((cy.chain_streak & 0xffffu) + 1u) | (16u << 16);
-        } else {
-            cy.chain_streak = (cy.chain_streak >> 16) ? ((cy.chain_streak >> 16) - 1u) << 16 : 0u;
-        }
-        if (pass > kMaxUnwrapPasses)
-            cy.refuse = true;
-        cy.stat_blocks += 1;
-        cy.stat_extra += (uint32_t)pass;
+        float est[kR];
+        fit_stage<EXACT>(c, lane, n, xd, den_s, xavg_s, fk, valid, raw, nvalid, lane_last, r_last, yring, ymask, cy, est);
         if constexpr (!EXACT) {
             // a call this tier cannot finish is the exact tier's from its first symbol on: stop here
             if (__any(cy.refuse)) {
@@ -1278,124 +1445,19 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         }
 
         // ================= de-rotation and hard decisions (reference cpp/psk_soft.cpp:484-566) =================
-        cf32 corr[kR];
-#pragma unroll
-        for (int r = 0; r < kR; r++) {
-            float phaseCorrection = 0.0f;
-            cf32 smp = s[r];
-            if (p.diff) {
-                cf32 last;
-                if (r == 0) {
-                    last.re = wave_up1(s[1].re, cy.last_re);
-                    last.im = wave_up1(s[1].im, cy.last_im);
-                } else {
-                    last = s[0];
-                }
-                smp = cdiv<true>(s[r], last);  // (__divsc3's recovery behind a wave-uniform test: a silent
-                                               //  stream divides by zero on every symbol)
-            } else {
-                phaseCorrection = m_pow2 ? (-est[r]) * inv_M : -est[r] / (float)M;
-            }
-            if (M == 4)
-                phaseCorrection = (float)((double)phaseCorrection + PSK_KD(kPi4, c));
-            float sn, cs;
-            sincosf_wave(phaseCorrection, &sn, &cs, c);
-            cf32 ph;
-            ph.re = 1.0f * cs;
-            ph.im = 1.0f * sn;
-            // (__mulsc3's recovery only ever changes a product with an infinite factor: impossible
-            // without differential decoding, where smp is a sample whose M-th power was finite)
-            corr[r] = (p.diff || EXACT) ? cmul<true>(smp, ph) : cmul<false>(smp, ph);
-        }
-
-        // ---- four output streams, two symbols per lane ----
-        unsigned short sym8[kR] = {0, 0};
-        if (p.bits && p.bpb == 3) {  // 8-PSK slicing with the whole wave active (the atan2f table lives in lanes 0-4)
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                sym8[r] = slice_8psk(corr[r].re, corr[r].im, atab);
-            }
-        }
-        if (valid[1]) {
-            if (p.soft) {
-                f4u v = {corr[0].re, corr[0].im, corr[1].re, corr[1].im};
-                store_f4u(g_soft + 2 * (size_t)i0, v);
-            }
-            if (p.phase) {
-                f2u v = {est[0], est[1]};
-                store_f2u(g_phase + i0, v);
-            }
-            if (!p.bits) {
-            } else if (p.bpb == 1) {
-                s2u v = {(short)(corr[0].re < 0), (short)(corr[1].re < 0)};
-                store_s2u(g_bits + i0, v);
-            } else if (p.bpb == 2) {  // quirk Q1 (float -> bool is "!= 0") unless the sign map was asked for
-                int a0, a1, b0, b1;
-                qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
-                qpsk_bits(corr[1].re, corr[1].im, qpsk_sign_map, b0, b1);
-                s4u v = {(short)a0, (short)a1, (short)b0, (short)b1};
-                store_s4u(g_bits + 2 * i0, v);
-            } else if (p.bpb == 3) {
-                const unsigned short a = sym8[0], b = sym8[1];
-                s2u v0 = {(short)(a & 1), (short)((a >> 1) & 1)};
-                s2u v1 = {(short)((a >> 2) & 1), (short)(b & 1)};
-                s2u v2 = {(short)((b >> 1) & 1), (short)((b >> 2) & 1)};
-                store_s2u(g_bits + 3 * i0, v0);
-                store_s2u(g_bits + 3 * i0 + 2, v1);
-                store_s2u(g_bits + 3 * i0 + 4, v2);
-            }
-        } else if (valid[0]) {  // an odd tail: one symbol
-            if (p.soft) {
-                g_soft[2 * (size_t)i0] = corr[0].re;
-                g_soft[2 * (size_t)i0 + 1] = corr[0].im;
-            }
-            if (p.phase)
-                g_phase[i0] = est[0];
-            if (!p.bits) {
-            } else if (p.bpb == 1) {
-                g_bits[i0] = (int16_t)(corr[0].re < 0);
-            } else if (p.bpb == 2) {
-                int a0, a1;
-                qpsk_bits(corr[0].re, corr[0].im, qpsk_sign_map, a0, a1);
-                g_bits[2 * i0] = (int16_t)a0;
-                g_bits[2 * i0 + 1] = (int16_t)a1;
-            } else if (p.bpb == 3) {
-                const unsigned short a = sym8[0];
-                g_bits[3 * i0] = (int16_t)(a & 1);
-                g_bits[3 * i0 + 1] = (int16_t)((a >> 1) & 1);
-                g_bits[3 * i0 + 2] = (int16_t)((a >> 2) & 1);
-            }
-        }
-
-        // ---- carries into the next block: the last valid position of this one ----
         {
-            const double ys = r_last ? ySum_l[1] : ySum_l[0];
-            const double xys = r_last ? xySum_l[1] : xySum_l[0];
-            const float e_ = r_last ? est[1] : est[0];
+            cf32 last_c;
+            last_c.re = cy.last_re;
+            last_c.im = cy.last_im;
+            output_stage<packet_global(S), EXACT>(p, c, i0, valid, s, est, last_c, atab, qpsk_sign_map, m_pow2, inv_M);
+        }
+        if (p.diff) {  // `last` only moves while differentialDecoding is on (cpp/psk_soft.cpp:486-491)
             const float sre = r_last ? s[1].re : s[0].re;
             const float sim = r_last ? s[1].im : s[0].im;
-            cy.ySum = read_lane(ys, lane_last);
-            cy.xySum = read_lane(xys, lane_last);
-            cy.est = read_lane(e_, lane_last);
-            {
-                // slope of the line just fitted, per symbol (LinearFit::m * xdelta, steady-state
-                // constants): only a hint for the next block's speculation, so approximate is fine
-                float m_hint;
-                (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
-                m_hint *= xd;
-                cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
-            }
-            if (p.diff) {  // `last` only moves while differentialDecoding is on (cpp/psk_soft.cpp:486-491)
-                cy.last_re = read_lane(sre, lane_last);
-                cy.last_im = read_lane(sim, lane_last);
-            }
-            const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
-            if (pts_last > 1) {  // calculateDenominator ran for the window size reached (cpp/psk_soft.cpp:81-83)
-                cy.den = den_last;
-                cy.xavg = xavg_last;
-            }
+            cy.last_re = read_lane(sre, lane_last);
+            cy.last_im = read_lane(sim, lane_last);
         }
-        cy.q = q0 + (uint32_t)nvalid;
+        }  // (!FRONT)
 
         if constexpr (!EXACT) {
             // every kScreenRefresh blocks recompute the float window sums from the energies in
@@ -1418,6 +1480,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if constexpr (H == 1)
             ring_base = er.wrap(ring_base + kB);
     }
+    if constexpr (FRONT && !EXACT)
+        cy.wmax = wmax_prev;
 }
 
 #undef g_soft

@@ -25,6 +25,9 @@ enum LfFlags : uint32_t {
     // de-rotated symbol, as the diagram at cpp/psk_soft.cpp:516-521 describes, instead of the
     // float->bool conversions of :523-526 that make every bit 0 (quirk Q1)
     PLAN_QPSK_SIGN_MAP = 2u,
+    // (not a LinearFit flag either) the call goes through the time-tiled kernels first (psk_tile_kernel.h): the
+    // wave-scan kernels behind them only pick it up if those hand it over (ChanState::guard == 1)
+    PLAN_TILED = 4u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582
@@ -60,6 +63,25 @@ struct ChanPlan {
     uint32_t lf_count0;  // LinearFit::count at the first next()
     uint32_t count0;     // psk_soft_i::count at loop start
     float lf_xdelta;     // LinearFit::xdelta after the prologue
+    // time-tiled kernels (PLAN_TILED): where this channel's symbols and tiles sit in the scratch of the call
+    uint32_t tile_blocks;  // 128-symbol blocks per tile
+    uint32_t tile_base;    // index of the channel's first TileInfo
+    uint32_t tile_pad;
+    uint64_t tile_off;     // offset of its first symbol in the raw-phase / picked-sample / estimate arrays
+};
+
+// What one tile of the time-tiled front kernel reports (psk_tile_kernel.h): the fit kernel, one wave per channel,
+// folds the tiles of its channel together and decides for the whole call.
+struct TileInfo {
+    uint32_t umax, umin1;  // exactness guard over the energies the tile summed exactly (FastCarry)
+    uint32_t refuse;       // the tile met something the screened timing does not carry
+    float gap_rel;         // smallest (best - runner-up) / (relative rounding bound) among its exact re-decisions
+    float wmax;            // largest window sum it saw
+    uint32_t stat_exact;   // blocks re-decided exactly
+    uint32_t last_k;       // timing index of its last symbol (the last tile's is the channel's)
+    float cap;             // largest sum of the whole call its screening thresholds allow for (FastCarry::cap)
+    float last0_re, last0_im;  // (tile 0, written by the fit kernel) psk_soft_i::last at the start of the call
+    uint32_t pad2[2];
 };
 
 // Data-dependent per-channel state that lives in HBM between calls.

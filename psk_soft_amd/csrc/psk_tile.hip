@@ -1,0 +1,218 @@
+// psk_tile.hip -- the time-tiled kernels (psk_tile_kernel.h): the fit and back kernels, which do not depend on
+// samplesPerBaud, and the dispatch to the per-samplesPerBaud instantiations of the front kernel (psk_tile_inst.hip).
+#include "psk_tile_kernel.h"
+
+namespace psk {
+
+// ---- fit: one wave per channel ----
+__global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                          ChanState *__restrict__ states, float2 *__restrict__ rings, uint32_t ring_cap,
+                                                          float *__restrict__ yvs, uint32_t fit_cap, uint32_t y_len,
+                                                          TileInfo *__restrict__ tiles, const float *__restrict__ t_raw,
+                                                          const float2 *__restrict__ t_s, float *__restrict__ t_est)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float *const yring = lds_dyn;
+    const uint32_t ymask = y_len - 1u;
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = list[blockIdx.x];
+    const ChanPlan &p = plans[bi];
+    if (!tile_plan_mine(p))
+        return;
+    const uint32_t ch = ch0 + bi;
+    ChanState *st = &states[ch];
+    const int n_out = (int)p.n_out;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    const int n_tiles = (n_blocks + (int)p.tile_blocks - 1) / (int)p.tile_blocks;
+    TileInfo *const ti = tiles + p.tile_base;
+
+    // ---- what the tiles of the front kernel found, folded over the call ----
+    unsigned umax = 0u, umin1 = 0xFFFFFFFFu, refuse_b = 0u, gap_b = 0x7F800000u, cap_b = 0x7F800000u, wmax_b = 0u;
+    int exact_blocks = 0;
+    for (int j = lane; j < n_tiles; j += kWave) {
+        const TileInfo t = ti[j];
+        umax = t.umax > umax ? t.umax : umax;
+        umin1 = t.umin1 < umin1 ? t.umin1 : umin1;
+        refuse_b |= t.refuse;
+        const unsigned g = __float_as_uint(t.gap_rel), cp = __float_as_uint(t.cap), w = __float_as_uint(t.wmax);
+        gap_b = g < gap_b ? g : gap_b;
+        cap_b = cp < cap_b ? cp : cap_b;
+        // (a NaN maximum -- bit pattern above inf's -- stays on top and fails both comparisons below)
+        wmax_b = w > wmax_b ? w : wmax_b;
+        exact_blocks += (int)t.stat_exact;
+    }
+    umax = wave_max_u32(umax);
+    umin1 = wave_min_u32(umin1);
+    gap_b = wave_min_u32(gap_b);
+    cap_b = wave_min_u32(cap_b);
+    wmax_b = wave_max_u32(wmax_b);
+    exact_blocks = __builtin_amdgcn_readlane(wave_scan_i32(exact_blocks), 63);
+    bool refuse = __any(refuse_b != 0u);
+    {
+        const float wmax = __uint_as_float(wmax_b);
+        // the screening thresholds of every tile must cover the drift of the reference's sums at the scale of the call
+        if (!(wmax <= __uint_as_float(cap_b)))
+            refuse = true;
+        // an exact re-decision closer than that drift: only the exactness guard (quirk Q8) can vouch for it
+        const bool ambiguous = !(__uint_as_float(gap_b) > wmax);
+        if (umin1 != 0xFFFFFFFFu && ambiguous) {
+            int emax = (int)(umax >> 23), emin = (int)((umin1 + 1u) >> 23);
+            emax = emax < 1 ? 1 : emax;
+            emin = emin < 1 ? 1 : emin;
+            const int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
+            if (24 + (emax - emin) + terms_log2 > 52)
+                refuse = true;
+        }
+    }
+    if (refuse) {
+        if (lane == 0)
+            st->guard = 1u;
+        return;
+    }
+
+    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
+    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
+    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
+    float *yv = yvs + (size_t)ch * fit_cap;
+    XView X;
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
+    X.L0 = p.ring_len0;
+
+    FastCarry cy;
+    call_prologue(p, st, yv, fit_cap, yring, ymask, lane, cy);
+    const float last0_re = cy.last_re, last0_im = cy.last_im;
+
+    const uint32_t n = p.lf_n;
+    const float xd = p.lf_xdelta;
+    float den_s = cy.den, xavg_s = cy.xavg;
+    if (n > 1)
+        fit_denominator(xd, n, den_s, xavg_s);
+    const FitKnown fk = fit_known(xd, n, den_s, xavg_s);
+    const float *raw_row = t_raw + p.tile_off;
+    float *est_row = t_est + p.tile_off;
+    float2 nxt = *reinterpret_cast<const float2 *>(raw_row + 2 * lane);
+    for (int c = 0; c < n_blocks; c++) {
+        const int i0 = c * kB + 2 * lane;
+        const float raw[kR] = {nxt.x, nxt.y};
+        if (c + 1 < n_blocks)  // (the next block's raw phases are on their way while this one is fitted)
+            nxt = *reinterpret_cast<const float2 *>(raw_row + i0 + kB);
+        const bool valid[kR] = {i0 < n_out, i0 + 1 < n_out};
+        const int rem = n_out - c * kB;
+        const int nvalid = rem < kB ? rem : kB;
+        const int lane_last = (nvalid - 1) >> 1, r_last = (nvalid - 1) & 1;
+        if (cy.chain_streak >> 16)
+            __builtin_amdgcn_s_setprio(PSK_CHAIN_PRIO);
+        else
+            __builtin_amdgcn_s_setprio(0);
+        float est[kR];
+        fit_stage<false>(c, lane, n, xd, den_s, xavg_s, fk, valid, raw, nvalid, lane_last, r_last, yring, ymask, cy, est);
+        if (__any(cy.refuse)) {
+            if (lane == 0)
+                st->guard = 1u;
+            return;
+        }
+        *reinterpret_cast<float2 *>(est_row + i0) = make_float2(est[0], est[1]);  // (rows padded to whole blocks)
+    }
+
+    cy.last_k = ti[n_tiles - 1].last_k;
+    cy.stat_exact_blocks = (uint32_t)exact_blocks;
+    if (p.diff) {  // psk_soft_i::last = the last sample output (cpp/psk_soft.cpp:486-491)
+        const float2 l = t_s[p.tile_off + (uint64_t)(n_out - 1)];
+        cy.last_re = l.x;
+        cy.last_im = l.y;
+    }
+    if (lane == 0) {  // the back kernel starts from the old one
+        ti[0].last0_re = last0_re;
+        ti[0].last0_im = last0_im;
+    }
+    call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
+}
+
+// ---- back: grid (tiles, channels of the launch) ----
+__global__ __launch_bounds__(64) void psk_tile_back_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                           const ChanState *__restrict__ states, const TileInfo *__restrict__ tiles,
+                                                           const float2 *__restrict__ t_s, const float *__restrict__ t_est)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = list[blockIdx.y];
+    const ChanPlan &p = plans[bi];
+    if (!tile_plan_mine(p) || states[ch0 + bi].guard != kGuardTiled)
+        return;
+    const int n_out = (int)p.n_out;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    const int c_begin = (int)(blockIdx.x * p.tile_blocks);
+    if (c_begin >= n_blocks)
+        return;
+    const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
+    const uint32_t M = p.M;
+    const bool m_pow2 = M != 0 && (M & (M - 1)) == 0;
+    const float inv_M = uni(1.0f / (float)(M ? M : 1));
+    const AtanTabDev atab = atan_tab_dev(lane);
+    const bool qpsk_sign_map = (p.lf_flags & PLAN_QPSK_SIGN_MAP) != 0;
+    const float2 *s_row = t_s + p.tile_off;
+    const float *est_row = t_est + p.tile_off;
+    for (int c = c_begin; c < c_end; c++) {
+        const int i0 = c * kB + 2 * lane;
+        const bool valid[kR] = {i0 < n_out, i0 + 1 < n_out};
+        const float4 sv = *reinterpret_cast<const float4 *>(s_row + i0);
+        const float2 ev = *reinterpret_cast<const float2 *>(est_row + i0);
+        cf32 s[kR];
+        s[0].re = sv.x, s[0].im = sv.y, s[1].re = sv.z, s[1].im = sv.w;
+        const float est[kR] = {ev.x, ev.y};
+        cf32 last_c;
+        last_c.re = last_c.im = 0.0f;
+        if (p.diff) {
+            if (c == 0) {
+                last_c.re = tiles[p.tile_base].last0_re;
+                last_c.im = tiles[p.tile_base].last0_im;
+            } else {
+                const float2 l = s_row[c * kB - 1];
+                last_c.re = l.x, last_c.im = l.y;
+            }
+        }
+        // (complex products with libgcc's recovery throughout: a sample that needs it was refused by the front kernel
+        // unless differential decoding divides by a silent one)
+        output_stage<true, true>(p, c, i0, valid, s, est, last_c, atab, qpsk_sign_map, m_pow2, inv_M);
+    }
+}
+
+#define PSK_TDECL(S) hipError_t launch_tile_front_S##S##_H1(PSK_TILE_FRONT_ARGS);
+PSK_TDECL(2) PSK_TDECL(3) PSK_TDECL(4) PSK_TDECL(5) PSK_TDECL(6) PSK_TDECL(7) PSK_TDECL(8) PSK_TDECL(9)
+PSK_TDECL(10) PSK_TDECL(11) PSK_TDECL(12) PSK_TDECL(13) PSK_TDECL(14) PSK_TDECL(15) PSK_TDECL(16)
+
+// window classes the front kernel is built for: numAvg <= 128 (one block of history, exact re-decisions from the LDS
+// energy ring), samplesPerBaud 2 .. 16
+bool tile_front_has(int S, int H) { return H == 1 && S >= 2 && S <= 16; }
+
+hipError_t launch_tile_front(int S, int H, PSK_TILE_FRONT_ARGS)
+{
+#define PSK_TCASE(Sv)       \
+    if (S == Sv && H == 1) \
+        return launch_tile_front_S##Sv##_H1(plans, list, ch0, nch, max_tiles, states, rings, ring_cap, r_len, tiles, t_raw, t_s, stream);
+    PSK_TCASE(2) PSK_TCASE(3) PSK_TCASE(4) PSK_TCASE(5) PSK_TCASE(6) PSK_TCASE(7) PSK_TCASE(8) PSK_TCASE(9)
+    PSK_TCASE(10) PSK_TCASE(11) PSK_TCASE(12) PSK_TCASE(13) PSK_TCASE(14) PSK_TCASE(15) PSK_TCASE(16)
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+                           uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
+                           const float2 *t_s, float *t_est, hipStream_t stream)
+{
+    if (!nch)
+        return hipSuccess;
+    hipLaunchKernelGGL(psk_tile_fit_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
+                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream)
+{
+    if (!nch || !max_tiles)
+        return hipSuccess;
+    hipLaunchKernelGGL(psk_tile_back_kernel, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, tiles, t_s, t_est);
+    return hipGetLastError();
+}
+
+}  // namespace psk

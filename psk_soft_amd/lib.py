@@ -89,6 +89,7 @@ class Stats(ctypes.Structure):
         ("unwrap_blocks", ctypes.c_uint64),
         ("timing_exact_blocks", ctypes.c_uint64),
         ("fit_chain_blocks", ctypes.c_uint64),
+        ("channels_tiled", ctypes.c_uint64),
     ]
 
 
@@ -256,6 +257,7 @@ class Handle:
 
     OPT_QPSK_SIGN_BITMAP = 1
     OPT_CONCURRENT_CLASSES = 2
+    OPT_TIME_TILED = 3  # 0 never, 1 where it pays (default), 2 wherever the kernels exist
 
     def set_option(self, option, value):
         _check(self._L.psk_soft_set_option(self._h, int(option), int(value)))

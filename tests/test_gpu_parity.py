@@ -964,7 +964,7 @@ def test_large_phase_estimate_is_bit_identical(oracle_mod, S, M, n):
     assert peak > 700.0, peak  # the regime this test is about was reached
 
 
-def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels):
+def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels, expect_tiled=None):
     """C channels through psk_soft_process_device (device-resident packets and output rows, rows on 128-byte
     boundaries as bench.py lays them out), `calls` = list of samples per call; the channels in check_channels are
     replayed through the oracle and compared bit for bit on all four streams."""
@@ -1009,6 +1009,8 @@ def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels):
             h.synchronize()
             st = h.stats()
             assert st["channels_fast"] == C and st["channels_sequential"] == 0, st
+            if expect_tiled is not None:
+                assert st["channels_tiled"] == expect_tiled, st
             soft = h.download(d_soft, (C, 2 * cap), np.float32)
             phase = h.download(d_phase, (C, cap), np.float32)
             sidx = h.download(d_sidx, (C, cap), np.int16)

@@ -1,0 +1,166 @@
+"""The time-tiled kernels (psk_soft_amd/csrc/psk_tile_kernel.h): calls of few channels and many symbols are cut
+along time -- timing recovery and raw phase per tile, the feedback unwrap and fit one wave per channel, de-rotation
+and slicing per tile again.  Same bar as everywhere: all four streams carry the oracle's bits, whatever the
+packetisation; a call the tiles cannot vouch for is redone by the wave-scan kernels."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import _handle, assert_parity, oracle_run, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiled_handle(n=1, mode=2):
+    from psk_soft_amd import lib as pl
+
+    h = _handle(n)
+    h.set_option(pl.Handle.OPT_TIME_TILED, mode)
+    return h
+
+
+CASES = [
+    # M, S, diff, numAvg, phaseAvg, N, packet
+    (4, 8, 0, 100, 50, 1 << 16, None),
+    (4, 8, 0, 100, 50, 1 << 16, 20000),
+    (4, 8, 1, 100, 50, 1 << 15, 9999),
+    (2, 8, 0, 100, 50, 1 << 15, None),
+    (2, 4, 1, 25, 10, 1 << 14, 5000),
+    (8, 10, 0, 100, 50, (1 << 16) + 7, None),
+    (8, 10, 1, 60, 200, 1 << 15, 12345),
+    (8, 9, 0, 128, 50, 1 << 15, None),
+    (4, 16, 0, 100, 300, 1 << 16, None),
+    (4, 5, 0, 7, 3, 1 << 14, 3001),
+    (4, 2, 0, 100, 50, 1 << 13, None),
+    (4, 3, 0, 1, 1, 1 << 13, 1000),
+    (4, 8, 0, 100, 50, 5000, 7),      # calls far smaller than a tile, most of them emitting nothing
+    (4, 13, 0, 64, 50, 1 << 15, None),
+]
+
+
+@pytest.mark.parametrize("M,S,diff,A,n,N,packet", CASES)
+def test_tiled_single_channel(oracle_mod, M, S, diff, A, n, N, packet):
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq = synth_channel(31 * M + S, M, S, N)
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=diff)
+    ref = oracle_run(oracle_mod, iq, props, packet=packet)
+    h = _tiled_handle()
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01, packet)
+    st = h.stats()
+    assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
+    if got["index"].size and (packet is None or packet > 8 * S):
+        assert st["channels_tiled"] == 1, st
+    assert_parity(got, ref, "tiled M%d S%d diff%d A%d n%d N%d pkt%s" % (M, S, diff, A, n, N, packet))
+    h.close()
+
+
+def test_tiled_matches_long_run(oracle_mod):
+    """BASELINE configs[1]: one channel, 2^20 samples in one call -- the case the tiles are for -- and the automatic
+    choice takes it there."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq = synth_channel(7, 4, 8, 1 << 20)
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100, phaseAvg=50)
+    ref = oracle_run(oracle_mod, iq, props)
+    h = _tiled_handle(mode=1)
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01)
+    st = h.stats()
+    assert st["channels_tiled"] == 1 and st["channels_fast"] == 1, st
+    assert_parity(got, ref, "tiled 2^20")
+    h.close()
+
+
+def test_tiled_mixed_batch_with_carried_state(oracle_mod):
+    """Several window classes in one batch, three calls with ragged cuts: every call starts from the state the call
+    before left (sample ring, LinearFit history and sums, differential `last`), tiled and not."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    n_ch = 24
+    props, iqs = [], []
+    for c in range(n_ch):
+        M = (2, 4, 8)[c % 3]
+        S = (8, 10, 4, 16, 6)[c % 5]
+        props.append(dict(samplesPerBaud=S, constelationSize=M, numAvg=(25, 100, 60)[c % 3], phaseAvg=(10, 50, 200)[(c // 3) % 3],
+                          differentialDecoding=int(c % 4 == 0)))
+        iqs.append(synth_channel(2000 + c, M, S, 30000 + 411 * c))
+    for mode_seq in ((2, 2, 2), (2, 0, 2), (0, 2, 0)):
+        h = _tiled_handle(n_ch)
+        h.configure(0, props)
+        got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(n_ch)]
+        cuts = [[0, 9000 + 17 * c, 9000 + 17 * c + 64 * (c % 5), iqs[c].size // 2] for c in range(n_ch)]
+        from psk_soft_amd import lib as pl
+
+        for k in range(3):
+            h.set_option(pl.Handle.OPT_TIME_TILED, mode_seq[k])
+            pk = [dict(data=iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], xdelta=0.01, sriChanged=(k == 0)) for c in range(n_ch)]
+            res = h.process_host(0, pk)
+            st = h.stats()
+            assert st["channels_fast"] == n_ch and st["channels_sequential"] == 0, st
+            if mode_seq[k] == 2 and k != 1:
+                assert st["channels_tiled"] == n_ch, st
+            if mode_seq[k] == 0:
+                assert st["channels_tiled"] == 0, st
+            for c in range(n_ch):
+                for key in got[c]:
+                    got[c][key].append(res[c][key])
+        for c in range(n_ch):
+            o = oracle_mod.OracleComponent()
+            for k2, v in props[c].items():
+                setattr(o, k2, v)
+            ref = dict(soft=[], bits=[], phase=[], index=[])
+            for k in range(3):
+                r = o.service(iqs[c][2 * cuts[c][k] : 2 * cuts[c][k + 1]], 0.01, sriChanged=(k == 0))
+                ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+            ref = {key: np.concatenate(v) for key, v in ref.items()}
+            assert_parity({key: np.concatenate(v) for key, v in got[c].items()}, ref, "modes %s ch %d" % (mode_seq, c))
+        h.close()
+
+
+def test_tiled_hands_over_what_it_cannot_carry(oracle_mod):
+    """A rectangular pulse makes every timing phase tie (the reference's own test stimulus): the tiles re-decide
+    exactly and stay; a NaN sample or a noisy unwrap is not theirs -- the call comes out of the wave-scan kernels
+    with the same bits."""
+    from psk_soft_amd.stimulus import synth_channel
+    from tests.test_oracle_reference_kat import reference_stimuli
+
+    M, diff, data, _ = reference_stimuli()["testNonDiffDecodeQPSK"]
+    props = dict(samplesPerBaud=8, constelationSize=M, numAvg=100)
+    ref = oracle_run(oracle_mod, data, props, xdelta=0.01)
+    h = _tiled_handle()
+    h.configure(0, [props])
+    got = run_gpu(h, 0, data, 0.01)
+    st = h.stats()
+    assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
+    assert_parity(got, ref, "rectangular pulse")
+    h.close()
+
+    iq = synth_channel(5, 4, 8, 1 << 15).copy()
+    iq[2 * 20000] = np.nan
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100)
+    ref = oracle_run(oracle_mod, iq, props)
+    h = _tiled_handle()
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01)
+    st = h.stats()
+    assert st["channels_tiled"] == 0 and st["channels_fast"] == 1 and st["channels_exact_timing"] == 1, st
+    assert_parity(got, ref, "NaN sample")
+    h.close()
+
+    iq = synth_channel(6, 4, 8, 1 << 15, sigma=0.3)
+    ref = oracle_run(oracle_mod, iq, props)
+    h = _tiled_handle()
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01)
+    assert h.stats()["channels_sequential"] == 0
+    assert_parity(got, ref, "10 dB")
+    h.close()
+
+
+def test_tiled_device_batch_auto(oracle_mod):
+    """64 channels x 2^16 samples through the device-pointer entry point: the automatic choice tiles them; spot
+    channels against the oracle."""
+    from tests.test_gpu_parity import _device_batch
+
+    _device_batch(oracle_mod, 4, 8, 100, 50, 64, [1 << 16, (1 << 16) - 24], (0, 1, 31, 63), expect_tiled=64)
