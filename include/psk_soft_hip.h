@@ -126,6 +126,10 @@ typedef struct psk_soft_stats {
                                      candidates did not verify: sums crossing a binade or zero)          */
     uint64_t channels_tiled;      /* of channels_fast: calls carried by the time-tiled kernels (few channels,
                                      long packets: the call is cut along time, see PSK_SOFT_OPT_TIME_TILED) */
+    uint64_t channels_parallel_fit; /* of channels_tiled: calls whose feedback unwrap and fit were guessed and
+                                     verified in parallel along time instead of walked block by block   */
+    uint64_t parallel_fit_refusals; /* why tiled calls that tried did not: bit 0 a ySum that rounds, bit 1 an xySum
+                                     certificate, bit 2 an unwrap count the guess got wrong (OR over the channels) */
 } psk_soft_stats_t;
 
 uint32_t psk_soft_abi_version(void);

@@ -35,10 +35,13 @@ hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipSt
 bool tile_front_has(int S, int H);
 hipError_t launch_tile_front(int S, int H, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                              const ChanState *states, const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw,
-                             float2 *t_s, hipStream_t stream);
+                             float2 *t_s, PfChan *pf_chan, hipStream_t stream);
 hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                            uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
-                           const float2 *t_s, float *t_est, hipStream_t stream);
+                           const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream);
+hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, ChanState *states,
+                       float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
+                       const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream);
 hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                             const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream);
 }  // namespace psk
@@ -231,6 +234,8 @@ struct psk_soft_handle {
     float *d_traw = nullptr, *d_test = nullptr;
     float2 *d_ts = nullptr;
     size_t tile_cap = 0, tile_sym_cap = 0;
+    psk::PfScratch pf{};   // ... and of the parallel fit (psk_pfit.h), same capacities; PfChan: one per channel of the handle
+    int opt_pfit = 1;      // PSK_SOFT_PARALLEL_FIT=0 (environment): time-tiled calls keep the block-by-block fit (A/B runs)
     hipEvent_t tile_ev = nullptr;
     hipStream_t tile_stream = nullptr;  // stream of the last call that used the scratch
     bool tile_ev_used = false;
@@ -276,6 +281,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_PARALLEL_FIT"))
+        h->opt_pfit = std::atoi(e) != 0;
     if (!h->dry) {
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
@@ -352,6 +359,9 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
         if (h->d_traw) (void)hipFree(h->d_traw);
         if (h->d_test) (void)hipFree(h->d_test);
         if (h->d_ts) (void)hipFree(h->d_ts);
+        for (void *q : {(void *)h->pf.k, (void *)h->pf.y, (void *)h->pf.S, (void *)h->pf.c, (void *)h->pf.tt, (void *)h->pf.xs,
+                        (void *)h->pf.tile, (void *)h->pf.blk, (void *)h->pf.walk, (void *)h->pf.chan})
+            if (q) (void)hipFree(q);
         if (h->tile_ev) (void)hipEventDestroy(h->tile_ev);
         for (auto &sl : h->stage) {
             if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -576,6 +586,8 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                     psk::ChanPlan &p = plans[h_list[off_SH[S][H] + i]];
                     const uint64_t nb = (p.n_out + 127u) / 128u;
                     p.lf_flags |= psk::PLAN_TILED;
+                    if (h->opt_pfit && p.lf_len0 == p.lf_n && p.lf_n >= 2)
+                        p.lf_flags |= psk::PLAN_PFIT;
                     p.tile_blocks = (uint32_t)K;
                     p.tile_base = (uint32_t)tile_count;
                     p.tile_off = tile_syms;
@@ -592,13 +604,31 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             if (h->d_traw) (void)hipFree(h->d_traw);
             if (h->d_test) (void)hipFree(h->d_test);
             if (h->d_ts) (void)hipFree(h->d_ts);
+            for (void *q : {(void *)h->pf.k, (void *)h->pf.y, (void *)h->pf.S, (void *)h->pf.c, (void *)h->pf.tt, (void *)h->pf.xs,
+                            (void *)h->pf.tile, (void *)h->pf.blk, (void *)h->pf.walk})
+                if (q) (void)hipFree(q);
             h->d_tiles = nullptr, h->d_traw = h->d_test = nullptr, h->d_ts = nullptr;
+            h->pf.k = nullptr, h->pf.y = nullptr, h->pf.S = h->pf.c = h->pf.xs = nullptr, h->pf.tt = nullptr, h->pf.tile = nullptr,
+            h->pf.blk = nullptr, h->pf.walk = nullptr;
             h->tile_cap = h->tile_sym_cap = 0;
             const size_t syms = tile_syms + tile_syms / 4, cnt = tile_count + tile_count / 4;
             PSK_HIP(hipMalloc((void **)&h->d_tiles, sizeof(psk::TileInfo) * cnt));
             PSK_HIP(hipMalloc((void **)&h->d_traw, sizeof(float) * syms));
             PSK_HIP(hipMalloc((void **)&h->d_test, sizeof(float) * syms));
             PSK_HIP(hipMalloc((void **)&h->d_ts, sizeof(float2) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.k, sizeof(int) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.y, sizeof(float) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.S, sizeof(double) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.c, sizeof(double) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.tt, sizeof(float) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.xs, sizeof(double) * syms));
+            PSK_HIP(hipMalloc((void **)&h->pf.tile, sizeof(psk::PfTile) * cnt));
+            PSK_HIP(hipMalloc((void **)&h->pf.blk, sizeof(psk::PfBlock) * (syms / 128u + 1u)));
+            PSK_HIP(hipMalloc((void **)&h->pf.walk, sizeof(psk::PfWalk) * (syms / 128u + 1u)));
+            if (!h->pf.chan) {
+                PSK_HIP(hipMalloc((void **)&h->pf.chan, sizeof(psk::PfChan) * h->nch));
+                PSK_HIP(hipMemset(h->pf.chan, 0, sizeof(psk::PfChan) * h->nch));
+            }
             h->tile_cap = cnt;
             h->tile_sym_cap = syms;
         }
@@ -665,9 +695,15 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             if (tiled_SH[S][H]) {
                 // (a call these cannot carry comes out with guard 1 and nothing committed: the launches below redo it)
                 PSK_HIP(psk::launch_tile_front(S, H, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
-                                               h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts, st));
+                                               h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts,
+                                               h->pf.chan, st));
+                if (h->opt_pfit)
+                    PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
+                                             h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts,
+                                             h->d_test, h->pf, st));
                 PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring,
-                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, st));
+                                             h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test,
+                                             h->pf, st));
                 PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                               h->d_tiles, h->d_ts, h->d_test, st));
             }
@@ -944,8 +980,12 @@ static void stats_add(psk_soft_stats_t *stats, uint32_t mode, const psk::ChanSta
             stats->channels_fast++;
             if (s.guard == 3u)
                 stats->channels_exact_timing++;
-            if (s.guard == 4u)
+            if (s.guard == 4u) {
                 stats->channels_tiled++;
+                if (s.stat_pfit & 1u)
+                    stats->channels_parallel_fit++;
+                stats->parallel_fit_refusals |= s.stat_pfit >> 1;
+            }
             stats->unwrap_blocks += s.stat_blocks;
             stats->unwrap_extra_passes += s.stat_extra;
             stats->timing_exact_blocks += s.stat_exact;

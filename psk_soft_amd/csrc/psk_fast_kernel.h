@@ -109,6 +109,7 @@ PSK_DEV void call_epilogue(const ChanPlan &p, ChanState *st, float *yv, uint32_t
             st->stat_extra = cy.stat_extra;
             st->stat_exact = cy.stat_exact_blocks;
             st->stat_chain = cy.stat_chain;
+            st->stat_pfit = 0u;
         }
     }
 }

@@ -28,6 +28,9 @@ enum LfFlags : uint32_t {
     // (not a LinearFit flag either) the call goes through the time-tiled kernels first (psk_tile_kernel.h): the
     // wave-scan kernels behind them only pick it up if those hand it over (ChanState::guard == 1)
     PLAN_TILED = 4u,
+    // ... and, of those, the call's feedback unwrap and fit are attempted in parallel along time (psk_pfit.h): the fit
+    // window is full at the start of the call
+    PLAN_PFIT = 8u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582
@@ -84,6 +87,43 @@ struct TileInfo {
     uint32_t pad2[2];
 };
 
+// Bookkeeping of the parallel fit (psk_pfit.h), in the scratch of the call next to the TileInfo records.
+struct PfTile {  // per tile
+    int jsum;     // numWraps increments of the tile
+    int pad;
+    double dsum;  // y[t] - y[t-n] over the tile
+    double xsum;  // term - c over the tile (plain double: only predicts the binade)
+};
+struct PfBlock {  // per 128-symbol block: what pf_xblock prepares for the walker
+    double bsum;      // term - c over the block (plain double: predicts the binade)
+    double a, b;      // the carried xySum s for which the block's transfer holds: a < s < b (empty: the walker runs the block)
+    double kmul;      // s * kmul has a fractional part iff s, in units of the block's q (mode B: of 2q), is odd
+    double D0s, D1s;  // what the block adds to s for an even / odd carried sum
+    int flags;        // bit 0 / 1: adding D0s / D1s flips the parity; bit 2: same q and mode as the block before, so the
+    int pad;          // parity carries over from it and need not be taken from s again
+};
+struct PfWalk {  // per 128-symbol block: what the walker found
+    double s_in;  // xySum carried into the block
+    int slow;     // the block's positions were produced by the walker itself: PfScratch::xs holds them
+    int pad;
+};
+struct PfChan {  // per channel of the call
+    uint32_t fail, done, slow_blocks, pad;
+    double ySum_c, xySum_c;  // LinearFit's sums at the call's first next(): carried, or rebuilt where reset() ran (pf_begin)
+};
+struct PfScratch {
+    int *k;       // numWraps (tile-local prefix, then absolute)
+    float *y;     // unwrapped phases
+    double *S;    // ySum after each symbol (tile-local prefix of the differences first)
+    double *c;    // fl(xdelta * ySum') per symbol
+    float *tt;    // the float term of :78
+    double *xs;   // xySum after each symbol
+    PfTile *tile;
+    PfBlock *blk;
+    PfWalk *walk;
+    PfChan *chan;
+};
+
 // Data-dependent per-channel state that lives in HBM between calls.
 struct ChanState {
     double lf_ySum;       // LinearFit::ySum
@@ -102,7 +142,7 @@ struct ChanState {
     uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
     uint32_t stat_exact;  // blocks whose timing argmax needed the exact double-precision pass
     uint32_t stat_chain;  // blocks whose LinearFit sums were redone by the reference-order chain (psk_fast_loop.h)
-    uint32_t reserved;
+    uint32_t stat_pfit;   // 1: the call's unwrap and fit were done in parallel along time (psk_pfit.h); else 2 * (why not: PfChan::fail)
 };
 
 }  // namespace psk

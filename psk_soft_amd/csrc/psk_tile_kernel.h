@@ -39,7 +39,7 @@ template <int SV, int HV>
 __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                             const ChanState *__restrict__ states, const float2 *__restrict__ rings,
                                                             uint32_t ring_cap, uint32_t r_len, TileInfo *__restrict__ tiles,
-                                                            float *__restrict__ t_raw, float2 *__restrict__ t_s)
+                                                            float *__restrict__ t_raw, float2 *__restrict__ t_s, PfChan *__restrict__ pf_chan)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     constexpr bool kDyn = ering_dynamic(SV);
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
     const int c_begin = (int)(blockIdx.x * p.tile_blocks);
     if (c_begin >= n_blocks)
         return;
+    if (blockIdx.x == 0 && lane == 0)  // the call's entry in the parallel fit's bookkeeping (psk_pfit.h: PfChan) starts clean
+        pf_chan[bi].fail = pf_chan[bi].done = pf_chan[bi].slow_blocks = 0u;
     const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
     const uint32_t ch = ch0 + bi;
     const float2 *ring_src = rings + ((size_t)ch * 2u + p.ring_src) * ring_cap;
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
 
 #define PSK_TILE_FRONT_ARGS                                                                                                    \
     const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, const ChanState *states,       \
-        const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw, float2 *t_s, hipStream_t stream
+        const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw, float2 *t_s, PfChan *pf_chan,          \
+        hipStream_t stream
 
 template <int SV, int HV>
 hipError_t launch_tile_front_inst(PSK_TILE_FRONT_ARGS)
@@ -112,7 +115,7 @@ hipError_t launch_tile_front_inst(PSK_TILE_FRONT_ARGS)
         return hipSuccess;
     const size_t lds_bytes = sizeof(float) * (ering_dynamic(SV) ? (size_t)SV * r_len : 0);
     hipLaunchKernelGGL((psk_tile_front_kernel<SV, HV>), dim3(max_tiles, nch), dim3(kWave), lds_bytes, stream, plans, list, ch0, states,
-                       rings, ring_cap, r_len, tiles, t_raw, t_s);
+                       rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan);
     return hipGetLastError();
 }
 

@@ -90,6 +90,8 @@ class Stats(ctypes.Structure):
         ("timing_exact_blocks", ctypes.c_uint64),
         ("fit_chain_blocks", ctypes.c_uint64),
         ("channels_tiled", ctypes.c_uint64),
+        ("channels_parallel_fit", ctypes.c_uint64),
+        ("parallel_fit_refusals", ctypes.c_uint64),
     ]
 
 
