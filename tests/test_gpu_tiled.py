@@ -51,6 +51,9 @@ def test_tiled_single_channel(oracle_mod, M, S, diff, A, n, N, packet):
     assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
     if got["index"].size and (packet is None or packet > 8 * S):
         assert st["channels_tiled"] == 1, st
+        # from the second call on the fit window is full: unwrap and fit go through the parallel path (psk_pfit.h)
+        if packet is not None and n >= 2:
+            assert st["channels_parallel_fit"] == 1 and st["parallel_fit_refusals"] == 0, st
     assert_parity(got, ref, "tiled M%d S%d diff%d A%d n%d N%d pkt%s" % (M, S, diff, A, n, N, packet))
     h.close()
 
@@ -156,6 +159,47 @@ def test_tiled_hands_over_what_it_cannot_carry(oracle_mod):
     assert h.stats()["channels_sequential"] == 0
     assert_parity(got, ref, "10 dB")
     h.close()
+
+
+def test_parallel_fit_verifies_or_steps_back(oracle_mod):
+    """The parallel fit guesses the unwrap counts from consecutive raw phases: right on a clean signal (all calls but
+    the first, whose fit window is still filling), wrong somewhere at 10 dB -- then the call is the block-by-block fit
+    kernel's, and the statistics say why.  Same bits either way."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100, phaseAvg=50)
+    for sigma, expect in ((0.01, True), (0.3, False)):
+        iq = synth_channel(77, 4, 8, 3 << 16, sigma=sigma)
+        ref = oracle_run(oracle_mod, iq, props, packet=1 << 16)
+        h = _tiled_handle()
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, 1 << 16)
+        st = h.stats()
+        assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
+        if expect:
+            assert st["channels_parallel_fit"] == 1 and st["parallel_fit_refusals"] == 0, st
+        else:
+            assert st["channels_parallel_fit"] == 0 and (st["channels_tiled"] == 0 or st["parallel_fit_refusals"] & 4), st
+        assert_parity(got, ref, "sigma %g" % sigma)
+        h.close()
+
+
+def test_parallel_fit_large_carrier_offset(oracle_mod):
+    """|phaseEstimate| runs into the hundreds of radians inside the calls (and wraps at their ends): the sums cross
+    binades, the walker's own blocks and the composed ones meet; 8-PSK, differential decoding, phaseAvg 200."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for M, S, n, diff, cfo in ((4, 8, 50, 0, 0.09), (8, 10, 200, 1, -0.05), (2, 4, 17, 0, 0.02)):
+        iq = synth_channel(91 + M, M, S, 3 << 15, cfo=cfo)
+        props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n, differentialDecoding=diff)
+        ref = oracle_run(oracle_mod, iq, props, packet=1 << 15)
+        h = _tiled_handle()
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, 1 << 15)
+        st = h.stats()
+        assert st["channels_parallel_fit"] == 1, st
+        assert_parity(got, ref, "cfo M%d" % M)
+        h.close()
 
 
 def test_tiled_device_batch_auto(oracle_mod):
