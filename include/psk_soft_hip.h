@@ -183,9 +183,10 @@ enum {
      * after the other on the caller's stream.  No effect on results. */
     PSK_SOFT_OPT_CONCURRENT_CLASSES = 2,
     /* Calls of few channels and many symbols are cut along time (tiles of a few hundred symbols spread over the
-     * machine, one wave per channel left for the feedback unwrap and fit): 1 (default) = where it pays (a window class
-     * of the call with at most 512 channels and at least 2048 symbols out per channel, numAvg <= 128,
-     * samplesPerBaud 2 .. 16), 0 = never, 2 = wherever the kernels exist (tests).  No effect on results.
+     * machine; the feedback unwrap and fit guessed in parallel and verified, else walked by one wave per channel):
+     * 1 (default) = where it pays (a window class of the call with at most 64 channels and 2048 symbols or more out
+     * per channel, or at most 512 channels and 24576 symbols; numAvg <= 128, samplesPerBaud 2 .. 16), 0 = never,
+     * 2 = wherever the kernels exist (tests).  No effect on results.
      * The environment variable PSK_SOFT_TIME_TILED (0 / 1 / 2) sets the default of new handles. */
     PSK_SOFT_OPT_TIME_TILED = 3
 };

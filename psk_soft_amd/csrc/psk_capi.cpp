@@ -190,9 +190,11 @@ inline size_t region_sidx(size_t in_cap) { return in_cap + in_cap + in_cap / 2 +
 inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap + in_cap / 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
-// time-tiled kernels, automatic choice: a class of at most this many channels whose longest call has at least this many
-// 128-symbol blocks; tiles of 2 .. 16 blocks, as many as make this number of tiles
-constexpr uint32_t kTiledMaxChannels = 512, kTiledMinBlocks = 16;
+// time-tiled kernels, automatic choice (measured, tools/tiled_sweep2.sh: QPSK, samplesPerBaud 8): a class of at most 64
+// channels whose longest call has at least 16 blocks of 128 symbols, or of at most 512 channels and 192 blocks (at 128
+// blocks the two paths are level there; above 512 channels the wave-scan kernels fill the machine by themselves);
+// tiles of 2 .. 16 blocks, as many as make kTiledTargetTiles tiles
+constexpr uint32_t kTiledFewChannels = 64, kTiledMinBlocksFew = 16, kTiledMaxChannels = 512, kTiledMinBlocks = 192;
 constexpr uint64_t kTiledTargetTiles = 4096;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
@@ -576,7 +578,8 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             for (int H = 1; H <= 8; H <<= 1) {
                 if (!res.need_SH[S][H] || !psk::tile_front_has(S, H))
                     continue;
-                if (h->opt_tiled == 1 && !(res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks))
+                if (h->opt_tiled == 1 && !((res.cnt_SH[S][H] <= kTiledFewChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocksFew) ||
+                                           (res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks)))
                     continue;
                 uint64_t K = res.blocks_SH[S][H] / kTiledTargetTiles;
                 K = K < 2 ? 2 : K > 16 ? 16 : K;

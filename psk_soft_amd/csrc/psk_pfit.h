@@ -381,9 +381,9 @@ PSK_DEV bool pf_x_ok(double s_c, const bool (&valid)[kR], const double (&c)[kR],
 }
 
 // ---- pf_xwalk: one wave per channel ----
-// the block's recurrence itself, as the block-by-block kernels run it: candidates from the true carried sum, their
-// certificate, else the recurrence lane after lane; the 128 sums go to xs_row, the last valid one is returned
-PSK_DEV double pf_walk_block(int lane, int b, int n_out, double s_c, const double *c_row, const float *t_row, double *xs_row)
+// the block's recurrence itself, as the block-by-block kernels run it: candidates from the true carried sum and their
+// certificate (try_grid), else the recurrence lane after lane; the 128 sums go to xs_row, the last valid one is returned
+PSK_DEV double pf_walk_block(int lane, int b, int n_out, double s_c, const double *c_row, const float *t_row, double *xs_row, bool try_grid)
 {
     const int i0 = b * kB + 2 * lane;
     const bool valid[kR] = {i0 < n_out, i0 + 1 < n_out};
@@ -392,8 +392,12 @@ PSK_DEV double pf_walk_block(int lane, int b, int n_out, double s_c, const doubl
     const double cc[kR] = {valid[0] ? cv.x : 0.0, valid[1] ? cv.y : 0.0};
     const double tt[kR] = {valid[0] ? (double)tv.x : 0.0, valid[1] ? (double)tv.y : 0.0};
     double xs[kR];
-    xysum_grid(lane, s_c, cc, tt, xs);
-    if (!pf_x_ok(s_c, valid, cc, tt, xs)) {
+    bool done = false;
+    if (try_grid) {  // (a block whose prepared range merely missed the sum is crossing a binade: the candidates cannot hold)
+        xysum_grid(lane, s_c, cc, tt, xs);
+        done = pf_x_ok(s_c, valid, cc, tt, xs);
+    }
+    if (!done) {
         double x = s_c;
 #pragma unroll 1
         for (int k = 0; k < kWave; k += PSK_CHAIN_UNROLL) {
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
                 s_in_mine = s_c;
                 slow_mine = 1;
             }
-            s_c = pf_walk_block(lane, b0 + f, n_out, s_c, c_row, t_row, xs_row);
+            s_c = pf_walk_block(lane, b0 + f, n_out, s_c, c_row, t_row, xs_row, !(a_f < b_f));
             slow_blocks++;
             par = -1;
             start = f + 1;
