@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--check", dest="check", action="store_true", default=True,
                     help="replay two channels of the run through the oracle afterwards and compare all four streams (default)")
     ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--no-few", dest="no_few", action="store_true",
+                    help="skip the one-channel measurement (BASELINE configs[1]) that the default run appends as `few_channels`")
     ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_CHANNELS",
                     help="strong scaling: TOTAL_CHANNELS channels shared by the ranks (BASELINE configs[3]: "
                          "--M 8 --S 10 --strong 32768) instead of --channels per rank")
@@ -182,6 +184,69 @@ def dry_rank(a):
         dist.barrier()
         dist.destroy_process_group()
     h.close()
+
+
+def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check):
+    """BASELINE configs[1], one channel on one GPU, as one long call per step (2^20 complex samples): the calls the
+    time-tiled kernels are for (psk_tile_kernel.h, psk_pfit.h), with the one-wave-per-channel kernels timed beside them
+    (PSK_SOFT_OPT_TIME_TILED = 0) and, with --check, the last call compared with the oracle bit for bit."""
+    from psk_soft_amd.stimulus import synth_channels_torch
+
+    N, C = 1 << 20, 1
+    iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED1000, periodic=True)
+    bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
+    cap = (N // S + 2 + 63) // 64 * 64
+    soft = torch.empty((C, 2 * cap), dtype=torch.float32, device=dev)
+    phase = torch.empty((C, cap), dtype=torch.float32, device=dev)
+    sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)
+    bits = torch.empty((C, max(bpb, 1) * cap), dtype=torch.int16, device=dev)
+    pk, out = (pl.Packet * C)(), (pl.Output * C)()
+    pk[0].data, pk[0].n_floats, pk[0].sri_xdelta, pk[0].sri_mode, pk[0].present = iq[0].data_ptr(), 2 * N, 0.01, 1, 1
+    out[0].soft, out[0].bits, out[0].phase, out[0].sampleIndex = soft[0].data_ptr(), bits[0].data_ptr(), phase[0].data_ptr(), sidx[0].data_ptr()
+    out[0].cap_symbols = cap
+    stream = torch.cuda.Stream(device=dev)
+    res, warm, steps = {}, 3, 10
+    for mode, key in ((0, "one_wave_per_channel"), (1, "time_tiled")):
+        h = pl.Handle(C, device=dev_index)
+        h.set_option(pl.Handle.OPT_TIME_TILED, mode)
+        h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=numAvg, phaseAvg=phaseAvg)
+        for _ in range(warm):
+            h.process_device(0, pk, out, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            h.process_device(0, pk, out, stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        st = h.stats()
+        res[key] = {"ms_per_call": ms, "Msamples_per_s": N / ms / 1e3,
+                    "kernel_stats": {k: st[k] for k in ("channels_tiled", "channels_parallel_fit", "parallel_fit_refusals", "fit_chain_blocks")}}
+        h.close()
+    res["workload"] = "%s, samplesPerBaud=%d, 1 channel x %d complex samples per call, numAvg=%d, phaseAvg=%d (BASELINE configs[1])" % (
+        {2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, N, numAvg, phaseAvg)
+    res["speedup"] = res["one_wave_per_channel"]["ms_per_call"] / res["time_tiled"]["ms_per_call"]
+    if check:
+        import numpy as np
+
+        from oracle import pyoracle as po
+
+        comp = po.OracleComponent()
+        comp.samplesPerBaud, comp.constelationSize, comp.numAvg, comp.phaseAvg = S, M, numAvg, phaseAvg
+        x = iq[0].cpu().numpy()
+        r = None
+        for _ in range(warm + steps):
+            r = comp.service(x, 0.01, sriChanged=False)
+        n_out = int(out[0].n_symbols)
+        same = all(np.array_equal(g.cpu().numpy().view(np.uint32 if g.dtype == torch.float32 else np.int16),
+                                  np.ascontiguousarray(w, np.float32 if g.dtype == torch.float32 else np.int16).view(
+                                      np.uint32 if g.dtype == torch.float32 else np.int16))
+                   for g, w in ((soft[0, : 2 * n_out], r.soft), (phase[0, :n_out], r.phase), (bits[0, : bpb * n_out], r.bits),
+                                (sidx[0, :n_out], r.index)))
+        res["check"] = {"calls_replayed": warm + steps, "all_four_streams_bit_identical": bool(same)}
+        assert same, "few_channels: the time-tiled path differs from the oracle"
+    return res
 
 
 def launch_ranks(a):
@@ -447,6 +512,9 @@ def main():
                 and np.array_equal(gp.view(np.uint32), np.ascontiguousarray(r.phase, np.float32).view(np.uint32))
         res["check"] = {"channels": [0, C - 1], "calls_replayed": a.warmup + a.steps, "bits_index_exact": True,
                         "soft_max_rel_err": worst, "soft_phase_bit_identical": bool(same)}
+
+    if rank == 0 and world == 1 and not a.mixed and not a.no_few:
+        res["few_channels"] = few_channels(pl, torch, dev, dev_index, M, S, a.numAvg, a.phaseAvg, a.check)
 
     if rank == 0:
         print(json.dumps(res))
