@@ -155,16 +155,16 @@ struct PlanSummary {
     uint32_t bad = 0;  // first refused channel (index into the batch)
     int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
-    bool need_SH[33][9] = {};
-    uint32_t cnt_SH[33][9] = {}, cnt_quiet = 0;  // channels per launch: each launch gets a compact list of its own
+    bool need_SH[33][17] = {};
+    uint32_t cnt_SH[33][17] = {}, cnt_quiet = 0;  // channels per launch: each launch gets a compact list of its own
     // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
     // y_len unwrapped phases (a power of two >= phaseAvg + 128) and, for numAvg <= 128, an energy
     // ring of r_len positions (even, >= numAvg + 128)
-    uint32_t max_n[33][9] = {}, max_A[33][9] = {};
+    uint32_t max_n[33][17] = {}, max_A[33][17] = {};
     uint32_t max_n_quiet = 0;  // ... and of the channels that emit nothing this call
     // time-tiled kernels: 128-symbol blocks of the class, in all and of its longest call
-    uint64_t blocks_SH[33][9] = {};
-    uint32_t max_blocks_SH[33][9] = {};
+    uint64_t blocks_SH[33][17] = {};
+    uint32_t max_blocks_SH[33][17] = {};
 };
 
 // One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
@@ -189,7 +189,14 @@ inline size_t region_bits(size_t in_cap) { return in_cap + in_cap + in_cap / 2; 
 inline size_t region_sidx(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap; }
 inline size_t region_total(size_t in_cap) { return in_cap + in_cap + in_cap / 2 + in_cap + in_cap / 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr uint32_t kFastFitMax = 2048 - 128;  // largest LDS phase ring of the wave-scan kernel (psk_wave.h kYRingMax) minus one block
+// Largest phaseAvg of the wave-scan kernels: their LDS ring of unwrapped phases holds phaseAvg + 128 values in a power
+// of two; 32768 floats (128 KiB) leave room for the energy ring next to it.  Channels with phaseAvg > kDeepFit are
+// launched apart from the others of their window class ("deep" classes, index H + 8): a ring that size allows one wave
+// per CU, and sized for the whole launch it would take the residency of thousands of ordinary channels with it.
+constexpr uint32_t kFastFitMax = 32768 - 128;
+constexpr uint32_t kDeepFit = 2048 - 128;
+const int kClassH[] = {1, 2, 4, 8, 9, 10, 12, 16};  // second index of the per-class tables: history blocks (+ 8: deep fit window)
+inline int class_H(int Hi) { return Hi > 8 ? Hi - 8 : Hi; }
 // time-tiled kernels, automatic choice (measured, tools/tiled_sweep2.sh: QPSK, samplesPerBaud 8): a class of at most 64
 // channels whose longest call has at least 16 blocks of 128 symbols, or of at most 512 channels and 192 blocks (at 128
 // blocks the two paths are level there; above 512 channels the wave-scan kernels fill the machine by themselves);
@@ -482,7 +489,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             if (p.mode == psk::PLAN_FAST) {
                 if (p.n_out) {
                     r.any_emit = true;
-                    const int Hh = psk::fast_hist_blocks(p.A);
+                    const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
                     r.need_SH[p.S][Hh] = true;
                     r.cnt_SH[p.S][Hh]++;
                     if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
@@ -546,21 +553,21 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // class in launch order
     uint32_t *const h_list = reinterpret_cast<uint32_t *>(h->h_plans[slot] + nch);
     const uint32_t *const d_list = reinterpret_cast<const uint32_t *>(h->d_plans[slot] + nch);
-    uint32_t off_SH[33][9] = {}, off_quiet = 0;
+    uint32_t off_SH[33][17] = {}, off_quiet = 0;
     {
         uint32_t run = res.cnt_quiet;
         for (int S : kFastS)
-            for (int H = 1; H <= 8; H <<= 1) {
+            for (int H : kClassH) {
                 off_SH[S][H] = run;
                 run += res.cnt_SH[S][H];
             }
-        uint32_t fill_SH[33][9] = {}, fill_quiet = 0;
+        uint32_t fill_SH[33][17] = {}, fill_quiet = 0;
         for (uint32_t i = 0; i < nch; i++) {
             const psk::ChanPlan &p = plans[i];
             if (p.mode != psk::PLAN_FAST)
                 continue;
             if (p.n_out) {
-                const int Hh = psk::fast_hist_blocks(p.A);
+                const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
                 h_list[off_SH[p.S][Hh] + fill_SH[p.S][Hh]++] = i;
             } else {
                 h_list[off_quiet + fill_quiet++] = i;
@@ -570,13 +577,13 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // Window classes of few channels and long calls go through the time-tiled kernels first (psk_tile_kernel.h): their
     // channels get a place in the scratch of the call -- symbols padded to whole blocks, K blocks to a tile, K chosen so
     // that the class makes a few thousand tiles.
-    bool tiled_SH[33][9] = {};
-    uint32_t tiles_max_SH[33][9] = {};
+    bool tiled_SH[33][17] = {};
+    uint32_t tiles_max_SH[33][17] = {};
     size_t tile_syms = 0, tile_count = 0;
     if (h->opt_tiled) {
         for (int S : kFastS)
-            for (int H = 1; H <= 8; H <<= 1) {
-                if (!res.need_SH[S][H] || !psk::tile_front_has(S, H))
+            for (int H : kClassH) {
+                if (!res.need_SH[S][H] || !psk::tile_front_has(S, class_H(H)))
                     continue;
                 if (h->opt_tiled == 1 && !((res.cnt_SH[S][H] <= kTiledFewChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocksFew) ||
                                            (res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks)))
@@ -663,12 +670,12 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         struct Cls {
             int S, H;
         };
-        Cls cls[33 * 4];
+        Cls cls[33 * 8];
         int n_cls = 0;
-        for (int H = 8; H >= 1; H >>= 1)
+        for (int k = 7; k >= 0; k--)
             for (int S : kFastS)
-                if (need_SH[S][H])
-                    cls[n_cls++] = Cls{S, H};
+                if (need_SH[S][kClassH[k]])
+                    cls[n_cls++] = Cls{S, kClassH[k]};
         const bool fork = n_cls > 1 && h->opt_fork;
         if (fork) {
             if (!h->aux_fork) {
@@ -694,10 +701,10 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 }
             }
             const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
-            const uint32_t r_len = H == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
+            const uint32_t r_len = class_H(H) == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
             if (tiled_SH[S][H]) {
                 // (a call these cannot carry comes out with guard 1 and nothing committed: the launches below redo it)
-                PSK_HIP(psk::launch_tile_front(S, H, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
+                PSK_HIP(psk::launch_tile_front(S, class_H(H), h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
                                                h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts,
                                                h->pf.chan, st));
                 if (h->opt_pfit)
@@ -711,7 +718,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                                               h->d_tiles, h->d_ts, h->d_test, st));
             }
             for (int exact = 0; exact <= 1; exact++)  // (the exact tier only works on the calls the screened tier left)
-                PSK_HIP(psk::launch_fast(S, H, exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
+                PSK_HIP(psk::launch_fast(S, class_H(H), exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
         }
         for (int a = 0; a < used_aux && a < kAuxStreams; a++) {

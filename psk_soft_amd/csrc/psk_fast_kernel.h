@@ -213,12 +213,27 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
     const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings, uint32_t ring_cap,    \
         float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len, hipStream_t stream
 
+// Dynamic LDS beyond the 64 KiB a kernel gets by default (a phase ring for phaseAvg in the thousands) has to be asked
+// for, once per kernel and size; `granted` is the kernel's own record of what it has asked for so far.
+inline hipError_t lds_grant(const void *kernel, size_t bytes, size_t &granted)
+{
+    if (bytes <= 65536 || bytes <= granted)
+        return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess)
+        granted = bytes;
+    return e;
+}
+
 template <int SV, int HV, bool EXACT>
 hipError_t launch_fast_inst(PSK_FAST_ARGS)
 {
     if (!nch)
         return hipSuccess;
     const size_t lds_bytes = sizeof(float) * ((size_t)y_len + (ering_dynamic(SV) ? (size_t)SV * r_len : 0));
+    static size_t granted = 0;
+    if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_fast_kernel<SV, HV, EXACT>), lds_bytes, granted))
+        return e;
     hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, list, ch0, states,
                        rings, ring_cap, yvs, fit_cap, y_len, r_len);
     return hipGetLastError();

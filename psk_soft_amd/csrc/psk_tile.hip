@@ -317,6 +317,9 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
 {
     if (!nch)
         return hipSuccess;
+    static size_t granted = 0;
+    if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_tile_fit_kernel), sizeof(float) * (size_t)y_len, granted))
+        return e;
     hipLaunchKernelGGL(psk_tile_fit_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
                        ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, sc.chan);
     return hipGetLastError();
@@ -330,6 +333,11 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
     if (!nch || !max_tiles)
         return hipSuccess;
     const dim3 grid(max_tiles, nch), wave(kWave);
+    static size_t granted_b = 0, granted_c = 0;
+    if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_begin_kernel), sizeof(float) * (size_t)y_len, granted_b))
+        return e;
+    if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_commit_kernel), sizeof(float) * (size_t)y_len, granted_c))
+        return e;
     hipLaunchKernelGGL(pf_begin_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, yvs, fit_cap, y_len, sc);
     hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, list, t_raw, sc);
     hipLaunchKernelGGL(pf_y_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc);

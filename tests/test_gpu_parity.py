@@ -326,10 +326,30 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     h.close()
 
 
+def test_deep_fit_windows(oracle_mod):
+    """phaseAvg in the thousands: the phase ring takes up to 128 KiB of LDS (dynamic LDS beyond 64 KiB is asked for per
+    kernel), the channel runs one wave per CU -- at the wave-scan kernels' speed, not the reference-order kernel's 4.7 us
+    per symbol.  Three calls: filling window, steady state, a window larger than a call."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for S, M, n, N in ((8, 4, 5000, 3 * 40000), (10, 8, 30000, 3 * 120000), (4, 2, 2049, 3 * 9000)):
+        props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n)
+        iq = synth_channel(4300 + S, M, S, N)
+        ref = oracle_run(oracle_mod, iq, props, packet=N // 3)
+        h = _handle(1, max_phase_avg=32768)
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, N // 3)
+        st = h.stats()
+        assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
+        assert_parity(got, ref, "phaseAvg %d" % n)
+        h.close()
+
+
 def test_long_phase_averages_stay_on_the_wave_scan_kernel(oracle_mod):
     """The LDS ring of unwrapped phases is sized by the host per launch (a power of two >= phaseAvg + 128, up
-    to 2048 floats): phaseAvg up to 1920 runs on the wave-scan kernel (it was 384), beyond that on the
-    reference-order kernel.  Mixed in one batch, ragged packets, a window that is still filling at first."""
+    to 32768 floats): phaseAvg up to 32640 runs on the wave-scan kernels (round 1: 1920), channels beyond 1920 in
+    launches of their own so that their ring does not take the residency of the others.  Mixed in one batch, ragged
+    packets, a window that is still filling at first."""
     from psk_soft_amd.stimulus import synth_channel
 
     rng = random.Random(41)
@@ -350,7 +370,7 @@ def test_long_phase_averages_stay_on_the_wave_scan_kernel(oracle_mod):
             for key in got[c]:
                 got[c][key].append(res[c][key])
     st = h.stats()
-    assert st["channels_sequential"] - st["channels_guard"] == 2, st  # phaseAvg 1921 and 3000
+    assert st["channels_sequential"] - st["channels_guard"] == 0 and st["channels_fast"] == len(cfgs), st
     for c in range(len(cfgs)):
         o = oracle_mod.OracleComponent()
         for kk, v in props[c].items():
