@@ -19,11 +19,15 @@ from psk_soft_amd import lib as pl  # noqa: E402
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
-# PSK_FUZZ_S / PSK_FUZZ_A: comma-separated lists that replace the default draws (to aim a run at some instantiations)
+# PSK_FUZZ_S / PSK_FUZZ_A / PSK_FUZZ_N: comma-separated lists that replace the default draws (to aim a run at some instantiations)
 S_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_S"].split(",")] if os.environ.get("PSK_FUZZ_S") else (
     [2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 33] + list(range(17, 33)))
 A_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_A"].split(",")] if os.environ.get("PSK_FUZZ_A") else (
     [1, 2, 3, 17, 25, 64, 100, 100, 127, 128, 129, 200, 256, 257, 400, 512, 520, 513, 1024])
+
+
+N_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_N"].split(",")] if os.environ.get("PSK_FUZZ_N") else (
+    [1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400, 900, 1920, 1921])  # phaseAvg
 
 
 def make_signal(rng, nrng, M, S, n):
@@ -86,7 +90,7 @@ def main():
             S = rng.choice(S_CHOICES)
             A = rng.choice(A_CHOICES)
             M = rng.choice([2, 4, 4, 8])
-            n = rng.choice([1, 2, 3, 10, 50, 50, 128, 200, 384, 385, 400, 900, 1920, 1921])
+            n = rng.choice(N_CHOICES)
             p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
             N = max(S * rng.choice([50, 300, 1200, 3000, 12000]), 64)
             sig = make_signal(rng, nrng, M, max(S, 1), N)
@@ -109,7 +113,7 @@ def main():
             if os.environ.get("PSK_FUZZ_DUMP") and int(os.environ["PSK_FUZZ_DUMP"]) == c:  # with a single-round replay: keep this channel's case
                 np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_case_sig.npy"), sig)
                 print("DUMPED channel %d: props=%s script=%s" % (c, p, ev))
-        h = pl.Handle(C, device=0, max_window_samples=33 * 1024 + 64, max_phase_avg=2048)
+        h = pl.Handle(C, device=0, max_window_samples=33 * 1024 + 64, max_phase_avg=max(2048, max(N_CHOICES)))
         h.configure(0, props)
         oracles = []
         for c in range(C):
