@@ -128,6 +128,8 @@ typedef struct psk_soft_stats {
                                      long packets: the call is cut along time, see PSK_SOFT_OPT_TIME_TILED) */
     uint64_t channels_parallel_fit; /* of channels_tiled: calls whose feedback unwrap and fit were guessed and
                                      verified in parallel along time instead of walked block by block   */
+    uint64_t channels_parallel_fit_second_round; /* of channels_parallel_fit: on the second guess of the unwrap counts
+                                     (the first, by consecutive raw phases, was wrong somewhere: a noisy stream)      */
     uint64_t parallel_fit_refusals; /* why tiled calls that tried did not: bit 0 a ySum that rounds, bit 1 an xySum
                                      certificate, bit 2 an unwrap count the guess got wrong (OR over the channels) */
 } psk_soft_stats_t;
@@ -188,7 +190,12 @@ enum {
      * per channel, or at most 512 channels and 24576 symbols; numAvg <= 128, samplesPerBaud 2 .. 16), 0 = never,
      * 2 = wherever the kernels exist (tests).  No effect on results.
      * The environment variable PSK_SOFT_TIME_TILED (0 / 1 / 2) sets the default of new handles. */
-    PSK_SOFT_OPT_TIME_TILED = 3
+    PSK_SOFT_OPT_TIME_TILED = 3,
+    /* The feedback unwrap and fit of a time-tiled call: 1 (default) = guessed in parallel along time and verified
+     * position by position, a second round on corrected unwrap counts enqueued for a while after a call whose first
+     * guess failed; 2 = the second round always enqueued; 0 = walked block by block, one wave per channel.  No effect on
+     * results.  Environment: PSK_SOFT_PARALLEL_FIT. */
+    PSK_SOFT_OPT_PARALLEL_FIT = 4
 };
 psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value);
 

@@ -41,7 +41,7 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
                            const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream);
 hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
-                       const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream);
+                       const float2 *t_s, float *t_est, const PfScratch &sc, bool second_round, hipStream_t stream);
 hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                             const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream);
 }  // namespace psk
@@ -244,7 +244,10 @@ struct psk_soft_handle {
     float2 *d_ts = nullptr;
     size_t tile_cap = 0, tile_sym_cap = 0;
     psk::PfScratch pf{};   // ... and of the parallel fit (psk_pfit.h), same capacities; PfChan: one per channel of the handle
-    int opt_pfit = 1;      // PSK_SOFT_PARALLEL_FIT=0 (environment): time-tiled calls keep the block-by-block fit (A/B runs)
+    int opt_pfit = 1;      // PSK_SOFT_PARALLEL_FIT (environment): 0 = time-tiled calls keep the block-by-block fit (A/B runs),
+                           // 2 = the second round of the parallel fit is always enqueued (tests), 1 = for a while after
+                           // a call reported a first guess that failed (pf.hint, a word the kernels write into page-locked memory)
+    int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
     hipEvent_t tile_ev = nullptr;
     hipStream_t tile_stream = nullptr;  // stream of the last call that used the scratch
     bool tile_ev_used = false;
@@ -291,7 +294,7 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_PARALLEL_FIT"))
-        h->opt_pfit = std::atoi(e) != 0;
+        h->opt_pfit = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (!h->dry) {
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
@@ -371,6 +374,7 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
         for (void *q : {(void *)h->pf.k, (void *)h->pf.y, (void *)h->pf.S, (void *)h->pf.c, (void *)h->pf.tt, (void *)h->pf.xs,
                         (void *)h->pf.tile, (void *)h->pf.blk, (void *)h->pf.walk, (void *)h->pf.chan})
             if (q) (void)hipFree(q);
+        if (h->pf.hint) (void)hipHostFree(h->pf.hint);
         if (h->tile_ev) (void)hipEventDestroy(h->tile_ev);
         for (auto &sl : h->stage) {
             if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -578,6 +582,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // channels get a place in the scratch of the call -- symbols padded to whole blocks, K blocks to a tile, K chosen so
     // that the class makes a few thousand tiles.
     bool tiled_SH[33][17] = {};
+    bool pf_second = false;
     uint32_t tiles_max_SH[33][17] = {};
     size_t tile_syms = 0, tile_count = 0;
     if (h->opt_tiled) {
@@ -638,12 +643,23 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             if (!h->pf.chan) {
                 PSK_HIP(hipMalloc((void **)&h->pf.chan, sizeof(psk::PfChan) * h->nch));
                 PSK_HIP(hipMemset(h->pf.chan, 0, sizeof(psk::PfChan) * h->nch));
+                PSK_HIP(hipHostMalloc((void **)&h->pf.hint, 64));
+                *h->pf.hint = 0u;
             }
             h->tile_cap = cnt;
             h->tile_sym_cap = syms;
         }
         if (!h->tile_ev)
             PSK_HIP(hipEventCreateWithFlags(&h->tile_ev, hipEventDisableTiming));
+        // second round of the parallel fit: for the next 16 tiled calls after one whose first guess of the unwrap counts
+        // failed somewhere (the kernels leave a note in page-locked memory; a late or lost note costs a call or two)
+        if (h->pf.hint && *static_cast<volatile uint32_t *>(h->pf.hint)) {
+            *static_cast<volatile uint32_t *>(h->pf.hint) = 0u;
+            h->pf_second_ttl = 16;
+        } else if (h->pf_second_ttl) {
+            h->pf_second_ttl--;
+        }
+        pf_second = h->opt_pfit == 2 || h->pf_second_ttl > 0;
         if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
             PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
     }
@@ -710,7 +726,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 if (h->opt_pfit)
                     PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                              h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts,
-                                             h->d_test, h->pf, st));
+                                             h->d_test, h->pf, pf_second, st));
                 PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring,
                                              h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test,
                                              h->pf, st));
@@ -992,9 +1008,13 @@ static void stats_add(psk_soft_stats_t *stats, uint32_t mode, const psk::ChanSta
                 stats->channels_exact_timing++;
             if (s.guard == 4u) {
                 stats->channels_tiled++;
-                if (s.stat_pfit & 1u)
+                if (s.stat_pfit & 1u) {
                     stats->channels_parallel_fit++;
-                stats->parallel_fit_refusals |= s.stat_pfit >> 1;
+                    if (s.stat_pfit & 0x100u)
+                        stats->channels_parallel_fit_second_round++;
+                } else {
+                    stats->parallel_fit_refusals |= s.stat_pfit >> 1;
+                }
             }
             stats->unwrap_blocks += s.stat_blocks;
             stats->unwrap_extra_passes += s.stat_extra;
@@ -1051,6 +1071,11 @@ psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)
         if (value < 0 || value > 2)
             return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: PSK_SOFT_OPT_TIME_TILED takes 0, 1 or 2");
         h->opt_tiled = value;
+        return PSK_SOFT_OK;
+    case PSK_SOFT_OPT_PARALLEL_FIT:
+        if (value < 0 || value > 2)
+            return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: PSK_SOFT_OPT_PARALLEL_FIT takes 0, 1 or 2");
+        h->opt_pfit = value;
         return PSK_SOFT_OK;
     default: return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: unknown option");
     }

@@ -7,7 +7,8 @@
 //
 //   pf_begin    the call's prologue (one wave per channel): the sums the first next() starts from -- LinearFit::reset()
 //               rebuilds them at the top of practically every call (quirks Q2 / Q3)
-//   pf_unwrap   numWraps by consecutive raw-phase differences: an integer prefix sum (per tile; tile totals)
+//   pf_unwrap   numWraps towards a smooth trajectory of the carrier (phasor averages of 16 symbols, unwrapped against each
+//               other by an integer prefix sum: per tile, tile totals) -- see there
 //   pf_y        y[t] = (float)(raw[t] + 2 pi numWraps[t])  (the tile's offset = the totals of the tiles before it)
 //   pf_ydiff    ySum: the running sum of float-valued terms is exact while the exponent range is small, hence equal to
 //               ySum(carried) + prefix sum of y[t] - y[t-n], whatever the order (per tile; tile totals)
@@ -26,8 +27,12 @@
 //   pf_commit   nothing failed anywhere: by induction from the carried state every value IS the reference's; end-of-call
 //               wrap and state commit as in the other kernels.
 //
-// A call that fails any check (a noisy unwrap, a sum that rounds) is left untouched and the block-by-block fit kernel
-// right behind redoes it.  Calls that start with the fit window still filling go there directly (PLAN_PFIT is not set).
+// A second round (pf_retry, then pf_y ... pf_verify again) takes the calls whose unwrap counts, and nothing else, failed the
+// first: its guess is what the first round's estimates -- off by a few hundredths of a radian around the wrong counts --
+// say the counts are.  The host enqueues it for a while after a call reported such a failure (a word in page-locked
+// memory, PfScratch::hint), so that clean streams do not pay for seven idle launches.
+// A call that fails any check in the end (a noisy unwrap, a sum that rounds) is left untouched and the block-by-block fit
+// kernel right behind redoes it.  Calls that start with the fit window still filling go there directly (PLAN_PFIT is not set).
 #ifndef PSK_PFIT_H
 #define PSK_PFIT_H
 
@@ -39,6 +44,8 @@ namespace psk {
 constexpr uint32_t kPfFailYSum = 1u, kPfFailXySum = 2u, kPfFailUnwrap = 4u;
 
 PSK_DEV bool pf_mine(const ChanPlan &p) { return p.mode == PLAN_FAST && (p.lf_flags & PLAN_PFIT) && p.n_out != 0; }
+// round 0: every call planned for the parallel fit; round 1: the calls whose unwrap counts, and nothing else, failed round 0
+PSK_DEV bool pf_in_round(const ChanPlan &p, const PfScratch &sc, uint32_t bi, int round) { return pf_mine(p) && (round == 0 || sc.chan[bi].retry != 0u); }
 
 // geometry of the wave's tile
 struct PfGeo {
@@ -68,8 +75,18 @@ PSK_DEV float pf_z(const ChanPlan &p, const float *y_row, const float *yv, uint3
 }
 
 // ---- pf_unwrap: grid (tiles, channels) ----
-__global__ __launch_bounds__(64) void pf_unwrap_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list,
-                                                       const float *__restrict__ t_raw, PfScratch sc)
+// The guess of the unwrap counts.  The reference unwraps every raw phase towards the estimate fed back from the fit,
+// a smooth line through the last phaseAvg values.  Unwrapping towards the previous RAW phase instead follows the noise:
+// at 20 dB it slips by 2 pi somewhere in most calls, and everything behind a slip is off.  So the guess is anchored to
+// a smooth trajectory of its own: the carrier's phasor averaged over sub-blocks of 16 symbols (noise / 4), the sub-block
+// angles unwrapped against each other (an integer prefix sum: per tile, tile totals), and every symbol unwrapped
+// towards the line through its sub-block's angle with the slope its neighbours give.  What is left are symbols whose
+// own noise comes within a few tenths of pi: single wrong counts, no slips -- the second round's business.
+// (The sub-block angles follow a carrier of up to ~0.15 rad per symbol; a channel whose last fit ran steeper than
+// kPfSteep keeps the plain guess by consecutive raw phases, good to pi per symbol on a clean signal.)
+constexpr float kPfSteep = 0.12f;
+__global__ __launch_bounds__(64) void pf_unwrap_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                       const ChanState *__restrict__ states, const float *__restrict__ t_raw, PfScratch sc)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
@@ -78,21 +95,64 @@ __global__ __launch_bounds__(64) void pf_unwrap_kernel(const ChanPlan *__restric
         return;
     const float *raw_row = t_raw + g.off;
     int *k_row = sc.k + g.off;
-    const float inv2pi = 0.15915494f;
+    const float inv2pi = 0.15915494f, two_pi = 6.2831853f;
+    const ChanState &st = states[ch0 + bi];
+    const bool steep = !(__builtin_fabsf(st.lf_m) < kPfSteep);  // (wave-uniform; NaN: steep)
     int run = 0;
-    for (int c = g.c_begin; c < g.c_end; c++) {
-        const int i0 = c * kB + 2 * g.lane;
-        const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
-        const float before = c ? raw_row[c * kB - 1] : rw.x;  // (the call's first symbol: its count comes from the carried estimate)
-        const float prev = wave_up1(rw.y, before);
-        int j0 = (int)__builtin_rintf((prev - rw.x) * inv2pi);
-        const int j1 = (int)__builtin_rintf((rw.x - rw.y) * inv2pi);
-        if (i0 == 0)
-            j0 = 0;
-        const int incl = wave_scan_i32(j0 + j1);
-        const int k0 = run + wave_up1(incl, 0) + j0;
-        *reinterpret_cast<int2 *>(k_row + i0) = make_int2(k0, k0 + j1);
-        run += __builtin_amdgcn_readlane(incl, 63);
+    if (steep) {
+        for (int c = g.c_begin; c < g.c_end; c++) {
+            const int i0 = c * kB + 2 * g.lane;
+            const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
+            const float before = c ? raw_row[c * kB - 1] : rw.x;
+            const float prev = wave_up1(rw.y, before);
+            int j0 = (int)__builtin_rintf((prev - rw.x) * inv2pi);
+            const int j1 = (int)__builtin_rintf((rw.x - rw.y) * inv2pi);
+            if (i0 == 0)  // (the call's first symbol: its count comes from the carried estimate, pf_y)
+                j0 = 0;
+            const int incl = wave_scan_i32(j0 + j1);
+            const int k0 = run + wave_up1(incl, 0) + j0;
+            *reinterpret_cast<int2 *>(k_row + i0) = make_int2(k0, k0 + j1);
+            run += __builtin_amdgcn_readlane(incl, 63);
+        }
+    } else {
+        // angle of the sub-block in front of the tile (the call's first: the carried estimate, already unwrapped)
+        float a_last = st.phaseEstimate;
+        if (g.c_begin > 0) {
+            const int t = g.c_begin * kB - 16 + 2 * (g.lane & 7);
+            const float2 rw = *reinterpret_cast<const float2 *>(raw_row + t);
+            float ph[2] = {__cosf(rw.x) + __cosf(rw.y), __sinf(rw.x) + __sinf(rw.y)};
+            wave_scan_f32_multi(ph);
+            a_last = atan2f(read_lane(ph[1], 7), read_lane(ph[0], 7));
+        }
+        const int grp = g.lane >> 3;
+        for (int c = g.c_begin; c < g.c_end; c++) {
+            const int i0 = c * kB + 2 * g.lane;
+            const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
+            // phasor sums of the eight sub-blocks (symbols past the end of the call left out): prefix sums over the wave,
+            // differenced at the sub-block ends
+            const bool v0 = i0 < g.n_out, v1 = i0 + 1 < g.n_out;
+            float ph[2] = {(v0 ? __cosf(rw.x) : 0.0f) + (v1 ? __cosf(rw.y) : 0.0f), (v0 ? __sinf(rw.x) : 0.0f) + (v1 ? __sinf(rw.y) : 0.0f)};
+            wave_scan_f32_multi(ph);
+            const int hi = (g.lane | 7) << 2, lo = ((g.lane & ~7) - 1) << 2;
+            const float re = bperm_addr(hi, ph[0]) - (grp ? bperm_addr(lo, ph[0]) : 0.0f);
+            const float im = bperm_addr(hi, ph[1]) - (grp ? bperm_addr(lo, ph[1]) : 0.0f);
+            const float a = atan2f(im, re);
+            // sub-block angles unwrapped against their predecessors
+            const float a_left = bperm_addr(lo, a);
+            const float a_prev = grp ? a_left : a_last;
+            const int jb = (g.lane & 7) == 0 ? (int)__builtin_rintf((a_prev - a) * inv2pi) : 0;
+            const int K = run + wave_scan_i32(jb);  // (inclusive: the lane's own sub-block counted)
+            const float U = a + two_pi * (float)(K - run);  // unwrapped relative to the block's start
+            // slope from the neighbouring sub-blocks (one-sided at the block's ends)
+            const float U_l = bperm_addr(((g.lane & ~7) - 8) << 2, U), U_r = bperm_addr(((g.lane & ~7) + 8) << 2, U);
+            const float slope = grp == 0 ? (U_r - U) * (1.0f / 16.0f) : grp == 7 ? (U - U_l) * (1.0f / 16.0f) : (U_r - U_l) * (1.0f / 32.0f);
+            const float dt0 = (float)(2 * (g.lane & 7)) - 7.5f;
+            const float line0 = a + slope * dt0, line1 = line0 + slope;
+            const int k0 = K + (int)__builtin_rintf((line0 - rw.x) * inv2pi), k1 = K + (int)__builtin_rintf((line1 - rw.y) * inv2pi);
+            *reinterpret_cast<int2 *>(k_row + i0) = make_int2(k0, k1);
+            run = __builtin_amdgcn_readlane(K, 63);
+            a_last = read_lane(a, 63);
+        }
     }
     if (g.lane == 0)
         sc.tile[g.tbase + g.tile].jsum = run;
@@ -100,21 +160,25 @@ __global__ __launch_bounds__(64) void pf_unwrap_kernel(const ChanPlan *__restric
 
 // ---- pf_y: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_y_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                  const ChanState *__restrict__ states, const float *__restrict__ t_raw, PfScratch sc)
+                                                  const ChanState *__restrict__ states, const float *__restrict__ t_raw, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
     PfGeo g;
-    if (!pf_mine(p) || !pf_geo(p, g))
+    if (!pf_in_round(p, sc, bi, round) || !pf_geo(p, g))
         return;
     const float *raw_row = t_raw + g.off;
     int *k_row = sc.k + g.off;
     float *y_row = sc.y + g.off;
     // numWraps of the call's first symbol from the carried estimate (cpp/psk_soft.cpp:477), then the tiles before this one
     int koff = 0;
-    for (int j = g.lane; j < g.tile; j += kWave) koff += sc.tile[g.tbase + j].jsum;
-    koff = __builtin_amdgcn_readlane(wave_scan_i32(koff), 63);
-    koff += (int)unwrap_count(states[ch0 + bi].phaseEstimate, (double)raw_row[0]);
+    if (round == 0) {
+        for (int j = g.lane; j < g.tile; j += kWave) koff += sc.tile[g.tbase + j].jsum;
+        koff = __builtin_amdgcn_readlane(wave_scan_i32(koff), 63);
+        // (plain guess: the first count from the carried estimate, cpp/psk_soft.cpp:477; the anchored guess starts from it)
+        if (!(__builtin_fabsf(states[ch0 + bi].lf_m) < kPfSteep))
+            koff += (int)unwrap_count(states[ch0 + bi].phaseEstimate, (double)raw_row[0]);
+    }  // (round 1: the counts are absolute already, corrected by pf_verify where the first guess was wrong)
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
         const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
@@ -131,12 +195,12 @@ __global__ __launch_bounds__(64) void pf_y_kernel(const ChanPlan *__restrict__ p
 
 // ---- pf_ydiff: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_ydiff_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                      const float *__restrict__ yvs, uint32_t fit_cap, PfScratch sc)
+                                                      const float *__restrict__ yvs, uint32_t fit_cap, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
     PfGeo g;
-    if (!pf_mine(p) || !pf_geo(p, g))
+    if (!pf_in_round(p, sc, bi, round) || !pf_geo(p, g))
         return;
     const float *y_row = sc.y + g.off;
     const float *yv = yvs + (size_t)(ch0 + bi) * fit_cap;
@@ -160,12 +224,12 @@ __global__ __launch_bounds__(64) void pf_ydiff_kernel(const ChanPlan *__restrict
 // ---- pf_ysum: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_ysum_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                      const ChanState *__restrict__ states, const float *__restrict__ yvs, uint32_t fit_cap,
-                                                     PfScratch sc)
+                                                     PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
     PfGeo g;
-    if (!pf_mine(p) || !pf_geo(p, g))
+    if (!pf_in_round(p, sc, bi, round) || !pf_geo(p, g))
         return;
     const float *y_row = sc.y + g.off;
     const float *yv = yvs + (size_t)(ch0 + bi) * fit_cap;
@@ -266,12 +330,12 @@ PSK_DEV void pf_resolve(int lane, bool modeB, bool P_c, const PfGrid &gr, double
 
 // ---- pf_xblock: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_xblock_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                       const ChanState *__restrict__ states, PfScratch sc)
+                                                       const ChanState *__restrict__ states, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
     PfGeo g;
-    if (!pf_mine(p) || !pf_geo(p, g))
+    if (!pf_in_round(p, sc, bi, round) || !pf_geo(p, g))
         return;
     const double *c_row = sc.c + g.off;
     const float *t_row = sc.tt + g.off;
@@ -431,11 +495,11 @@ PSK_DEV double pf_from_lane(double v, int src)
 // not its predecessor's -- stops the scan: everything in front of it stands, it is dealt with on its own, the scan resumes
 // behind it.
 __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list,
-                                                      const PfBlock *__restrict__ blk_all, PfScratch sc)
+                                                      const PfBlock *__restrict__ blk_all, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.x];
     const ChanPlan &p = plans[bi];
-    if (!pf_mine(p))
+    if (!pf_in_round(p, sc, bi, round))
         return;
     const int lane = threadIdx.x & 63;
     const int n_out = (int)p.n_out;
@@ -541,12 +605,12 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
 // ---- pf_verify: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                        const ChanState *__restrict__ states, const float *__restrict__ t_raw,
-                                                       float *__restrict__ t_est, PfScratch sc)
+                                                       float *__restrict__ t_est, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
     PfGeo g;
-    if (!pf_mine(p) || !pf_geo(p, g))
+    if (!pf_in_round(p, sc, bi, round) || !pf_geo(p, g))
         return;
     const ChanState &st = states[ch0 + bi];
     const float *raw_row = t_raw + g.off;
@@ -595,10 +659,13 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
         const bool sure0 = __builtin_fabsf(est_prev0 - y.x) < 3.0f && __builtin_fabsf(y.x) < 65536.0f;
         const bool sure1 = __builtin_fabsf(est[0] - y.y) < 3.0f && __builtin_fabsf(y.y) < 65536.0f;
         if (!vote_all((sure0 || !valid[0]) && (sure1 || !valid[1]))) {
-            const bool k0_ok = unwrap_count(est_prev0, (double)rw.x, c) == (long long)k.x;
-            const bool k1_ok = unwrap_count(est[0], (double)rw.y, c) == (long long)k.y;
-            if ((valid[0] && !k0_ok) || (valid[1] && !k1_ok))
+            const long long w0 = unwrap_count(est_prev0, (double)rw.x, c), w1 = unwrap_count(est[0], (double)rw.y, c);
+            if ((valid[0] && w0 != (long long)k.x) || (valid[1] && w1 != (long long)k.y)) {
                 bad_k = true;
+                // what the (slightly off) estimates of this round say the counts are: the second round's guess
+                if (round == 0 && w0 == (long long)(int)w0 && w1 == (long long)(int)w1)
+                    *reinterpret_cast<int2 *>(sc.k + g.off + i0) = make_int2((int)w0, (int)w1);
+            }
         }
         *reinterpret_cast<float2 *>(est_row + i0) = make_float2(est[0], est[1]);
     }
@@ -606,6 +673,21 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
         atomicOr(&sc.chan[bi].fail, kPfFailXySum);
     if (vote_any(bad_k) && g.lane == 0)
         atomicOr(&sc.chan[bi].fail, kPfFailUnwrap);
+}
+
+// ---- pf_retry: between the rounds, one wave per channel ----
+__global__ __launch_bounds__(64) void pf_retry_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, PfScratch sc)
+{
+    const uint32_t bi = list[blockIdx.x];
+    if (!pf_mine(plans[bi]) || (threadIdx.x & 63) != 0)
+        return;
+    const uint32_t f = sc.chan[bi].fail;
+    if (f & kPfFailUnwrap)
+        *sc.hint = 1u;
+    const bool again = f == kPfFailUnwrap;  // (a sum that rounds would round again)
+    sc.chan[bi].retry = again ? 1u : 0u;
+    if (again)
+        sc.chan[bi].fail = 0u;
 }
 
 }  // namespace psk

@@ -108,7 +108,8 @@ struct PfWalk {  // per 128-symbol block: what the walker found
     int pad;
 };
 struct PfChan {  // per channel of the call
-    uint32_t fail, done, slow_blocks, pad;
+    uint32_t fail, done, slow_blocks;
+    uint32_t retry;  // the first guess of the unwrap counts failed and nothing else did: a second round runs on corrected counts
     double ySum_c, xySum_c;  // LinearFit's sums at the call's first next(): carried, or rebuilt where reset() ran (pf_begin)
 };
 struct PfScratch {
@@ -122,6 +123,7 @@ struct PfScratch {
     PfBlock *blk;
     PfWalk *walk;
     PfChan *chan;
+    uint32_t *hint;  // page-locked host word: set when a call's first guess of the unwrap counts failed (the host then enqueues second rounds)
 };
 
 // Data-dependent per-channel state that lives in HBM between calls.
@@ -142,7 +144,8 @@ struct ChanState {
     uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
     uint32_t stat_exact;  // blocks whose timing argmax needed the exact double-precision pass
     uint32_t stat_chain;  // blocks whose LinearFit sums were redone by the reference-order chain (psk_fast_loop.h)
-    uint32_t stat_pfit;   // 1: the call's unwrap and fit were done in parallel along time (psk_pfit.h); else 2 * (why not: PfChan::fail)
+    uint32_t stat_pfit;   // bit 0: the call's unwrap and fit were done in parallel along time (psk_pfit.h), bit 8: in the second
+                          // round; else 2 * (why not: PfChan::fail)
 };
 
 }  // namespace psk

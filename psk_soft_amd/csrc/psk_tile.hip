@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
                                                           float *__restrict__ yvs, uint32_t fit_cap, uint32_t y_len,
                                                           TileInfo *__restrict__ tiles, const float *__restrict__ t_raw,
                                                           const float2 *__restrict__ t_s, float *__restrict__ t_est,
-                                                          const PfChan *__restrict__ pf_chan)
+                                                          const PfChan *__restrict__ pf_chan, uint32_t *__restrict__ pf_hint)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float *const yring = lds_dyn;
@@ -139,8 +139,11 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
         ti[0].last0_im = last0_im;
     }
     call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
-    if ((p.lf_flags & PLAN_PFIT) && lane == 0)
+    if ((p.lf_flags & PLAN_PFIT) && lane == 0) {
         st->stat_pfit = pf_chan[bi].fail << 1;  // (statistics: why the parallel fit left the call to this kernel)
+        if (pf_chan[bi].fail & kPfFailUnwrap)
+            *pf_hint = 1u;
+    }
 }
 
 // ---- pf_begin: one wave per channel (psk_pfit.h) ----
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(64) void pf_commit_kernel(const ChanPlan *__restric
     }
     call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
     if (lane == 0)
-        st->stat_pfit = 1u;
+        st->stat_pfit = 1u | (sc.chan[bi].retry ? 0x100u : 0u);
 }
 
 // ---- back: grid (tiles, channels of the launch) ----
@@ -321,14 +324,15 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_tile_fit_kernel), sizeof(float) * (size_t)y_len, granted))
         return e;
     hipLaunchKernelGGL(psk_tile_fit_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
-                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, sc.chan);
+                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, sc.chan, sc.hint);
     return hipGetLastError();
 }
 
-// the parallel fit of a class (psk_pfit.h): eight launches between the front kernel and the block-by-block fit kernel
+// the parallel fit of a class (psk_pfit.h): nine launches between the front kernel and the block-by-block fit kernel, seven more
+// with a second round
 hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
-                       const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream)
+                       const float2 *t_s, float *t_est, const PfScratch &sc, bool second_round, hipStream_t stream)
 {
     if (!nch || !max_tiles)
         return hipSuccess;
@@ -339,13 +343,17 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_commit_kernel), sizeof(float) * (size_t)y_len, granted_c))
         return e;
     hipLaunchKernelGGL(pf_begin_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, yvs, fit_cap, y_len, sc);
-    hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, list, t_raw, sc);
-    hipLaunchKernelGGL(pf_y_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc);
-    hipLaunchKernelGGL(pf_ydiff_kernel, grid, wave, 0, stream, plans, list, ch0, yvs, fit_cap, sc);
-    hipLaunchKernelGGL(pf_ysum_kernel, grid, wave, 0, stream, plans, list, ch0, states, yvs, fit_cap, sc);
-    hipLaunchKernelGGL(pf_xblock_kernel, grid, wave, 0, stream, plans, list, ch0, states, sc);
-    hipLaunchKernelGGL(pf_xwalk_kernel, dim3(nch), wave, 0, stream, plans, list, sc.blk, sc);
-    hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, t_est, sc);
+    hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc);
+    for (int round = 0; round <= (second_round ? 1 : 0); round++) {
+        if (round)
+            hipLaunchKernelGGL(pf_retry_kernel, dim3(nch), wave, 0, stream, plans, list, sc);
+        hipLaunchKernelGGL(pf_y_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc, round);
+        hipLaunchKernelGGL(pf_ydiff_kernel, grid, wave, 0, stream, plans, list, ch0, yvs, fit_cap, sc, round);
+        hipLaunchKernelGGL(pf_ysum_kernel, grid, wave, 0, stream, plans, list, ch0, states, yvs, fit_cap, sc, round);
+        hipLaunchKernelGGL(pf_xblock_kernel, grid, wave, 0, stream, plans, list, ch0, states, sc, round);
+        hipLaunchKernelGGL(pf_xwalk_kernel, dim3(nch), wave, 0, stream, plans, list, sc.blk, sc, round);
+        hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, t_est, sc, round);
+    }
     hipLaunchKernelGGL(pf_commit_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings, ring_cap,
                        yvs, fit_cap, y_len, tiles, t_s, t_est, sc);
     return hipGetLastError();

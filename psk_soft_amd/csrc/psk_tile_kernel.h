@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
     if (c_begin >= n_blocks)
         return;
     if (blockIdx.x == 0 && lane == 0)  // the call's entry in the parallel fit's bookkeeping (psk_pfit.h: PfChan) starts clean
-        pf_chan[bi].fail = pf_chan[bi].done = pf_chan[bi].slow_blocks = 0u;
+        pf_chan[bi].fail = pf_chan[bi].done = pf_chan[bi].slow_blocks = pf_chan[bi].retry = 0u;
     const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
     const uint32_t ch = ch0 + bi;
     const float2 *ring_src = rings + ((size_t)ch * 2u + p.ring_src) * ring_cap;

@@ -91,6 +91,7 @@ class Stats(ctypes.Structure):
         ("fit_chain_blocks", ctypes.c_uint64),
         ("channels_tiled", ctypes.c_uint64),
         ("channels_parallel_fit", ctypes.c_uint64),
+        ("channels_parallel_fit_second_round", ctypes.c_uint64),
         ("parallel_fit_refusals", ctypes.c_uint64),
     ]
 
@@ -260,6 +261,7 @@ class Handle:
     OPT_QPSK_SIGN_BITMAP = 1
     OPT_CONCURRENT_CLASSES = 2
     OPT_TIME_TILED = 3  # 0 never, 1 where it pays (default), 2 wherever the kernels exist
+    OPT_PARALLEL_FIT = 4  # tiled calls: 0 fit block by block, 1 parallel fit with the second round on demand (default), 2 always
 
     def set_option(self, option, value):
         _check(self._L.psk_soft_set_option(self._h, int(option), int(value)))

@@ -178,9 +178,42 @@ def test_parallel_fit_verifies_or_steps_back(oracle_mod):
         assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
         if expect:
             assert st["channels_parallel_fit"] == 1 and st["parallel_fit_refusals"] == 0, st
-        else:
-            assert st["channels_parallel_fit"] == 0 and (st["channels_tiled"] == 0 or st["parallel_fit_refusals"] & 4), st
+        else:  # (refused by the front tiles altogether, or the unwrap counts did not verify)
+            assert st["channels_parallel_fit"] == 1 or st["channels_tiled"] == 0 or st["parallel_fit_refusals"] & 4, st
         assert_parity(got, ref, "sigma %g" % sigma)
+        h.close()
+
+
+def test_parallel_fit_second_round(oracle_mod):
+    """16 dB: the first guess of the unwrap counts (towards a smoothed carrier trajectory) misses single symbols in
+    some calls; the second round, on the counts the first round's estimates give, verifies.  With the round always
+    enqueued (option 2), and on demand (the default: enqueued after a call reported a miss)."""
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    C, N, calls = 16, 1 << 15, 8
+    props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100, phaseAvg=50)
+    iqs = [synth_channel(100 + c, 4, 8, calls * N, sigma=0.15) for c in range(C)]
+    refs = [oracle_run(oracle_mod, iqs[c], props, packet=N) for c in range(C)]
+    for mode in (2, 1):
+        h = _tiled_handle(C)
+        h.set_option(pl.Handle.OPT_PARALLEL_FIT, mode)
+        h.configure(0, [props] * C)
+        got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
+        second = par = 0
+        for k in range(calls):
+            res = h.process_host(0, [dict(data=iq[2 * k * N : 2 * (k + 1) * N], xdelta=0.01, sriChanged=(k == 0)) for iq in iqs])
+            st = h.stats()
+            assert st["channels_fast"] == C and st["channels_sequential"] == 0, st
+            second += st["channels_parallel_fit_second_round"]
+            par += st["channels_parallel_fit"]
+            for c in range(C):
+                for key in got[c]:
+                    got[c][key].append(res[c][key])
+        assert par >= (calls - 1) * C * 3 // 4, (mode, par)
+        assert second >= 1, (mode, second, par)
+        for c in range(C):
+            assert_parity({key: np.concatenate(v) for key, v in got[c].items()}, refs[c], "mode %d ch %d" % (mode, c))
         h.close()
 
 
