@@ -16,7 +16,7 @@ cd $GRAFT_REPO_ROOT
 for r in $(seq 1 $reps); do
   for i in $(seq 0 $((n-1))); do
     cp /tmp/lib_variant_$i.so psk_soft_amd/libpsk_soft_hip.so
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-check $bargs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('RUN $i %.4f %d'%(d['roofline']['launch_ms_avg'], d['kernel_stats']['fit_chain_blocks']))"
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-check --no-few $bargs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('RUN $i %.4f %d'%(d['roofline']['launch_ms_avg'], d['kernel_stats']['fit_chain_blocks']))"
   done
 done | tee /tmp/ab.log
 python - "$@" <<'PY'

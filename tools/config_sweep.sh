@@ -3,7 +3,7 @@
 # one bench.py run each (--check: two channels replayed through the oracle), one line per configuration
 cd $GRAFT_REPO_ROOT
 run() {
-  python bench.py --steps 20 --warmup 10 --no-cpu-baseline --check "$@" 2>/dev/null | tail -1 | python -c "
+  python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-few --check "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']; k = d['kernel_stats']; c = d['check']
 print('%-44s ms %.3f  frac %.3f  of-ceiling %.3f  exact-blocks %d  extra-passes %d  seq %d  check bits %s soft %.1e' % (

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in $CH; do
   out=$R/gpurun_out/$tag/c$c
   mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --channels $c --nsamp $N --steps 10 --warmup 3 --no-cpu-baseline --no-check > $out/log.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --channels $c --nsamp $N --steps 10 --warmup 3 --no-cpu-baseline --no-check --no-few > $out/log.txt 2>&1
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   echo "== $c channels x $N samples"
   if [ -n "$f" ]; then python3 - "$f" <<'PY'
