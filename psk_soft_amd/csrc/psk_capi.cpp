@@ -627,28 +627,33 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             h->pf.blk = nullptr, h->pf.walk = nullptr;
             h->tile_cap = h->tile_sym_cap = 0;
             const size_t syms = tile_syms + tile_syms / 4, cnt = tile_count + tile_count / 4;
-            PSK_HIP(hipMalloc((void **)&h->d_tiles, sizeof(psk::TileInfo) * cnt));
-            PSK_HIP(hipMalloc((void **)&h->d_traw, sizeof(float) * syms));
-            PSK_HIP(hipMalloc((void **)&h->d_test, sizeof(float) * syms));
-            PSK_HIP(hipMalloc((void **)&h->d_ts, sizeof(float2) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.k, sizeof(int) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.y, sizeof(float) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.S, sizeof(double) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.c, sizeof(double) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.tt, sizeof(float) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.xs, sizeof(double) * syms));
-            PSK_HIP(hipMalloc((void **)&h->pf.tile, sizeof(psk::PfTile) * cnt));
-            PSK_HIP(hipMalloc((void **)&h->pf.blk, sizeof(psk::PfBlock) * (syms / 128u + 1u)));
-            PSK_HIP(hipMalloc((void **)&h->pf.walk, sizeof(psk::PfWalk) * (syms / 128u + 1u)));
-            if (!h->pf.chan) {
-                PSK_HIP(hipMalloc((void **)&h->pf.chan, sizeof(psk::PfChan) * h->nch));
-                PSK_HIP(hipMemset(h->pf.chan, 0, sizeof(psk::PfChan) * h->nch));
-                PSK_HIP(hipHostMalloc((void **)&h->pf.hint, 64));
-                *h->pf.hint = 0u;
+            // (out of device memory: the call does without -- the wave-scan kernels carry everything on their own)
+            auto grab = [](auto **q, size_t bytes) { return hipMalloc((void **)q, bytes) == hipSuccess; };
+            bool got = grab(&h->d_tiles, sizeof(psk::TileInfo) * cnt) && grab(&h->d_traw, sizeof(float) * syms) &&
+                       grab(&h->d_test, sizeof(float) * syms) && grab(&h->d_ts, sizeof(float2) * syms) &&
+                       grab(&h->pf.k, sizeof(int) * syms) && grab(&h->pf.y, sizeof(float) * syms) && grab(&h->pf.S, sizeof(double) * syms) &&
+                       grab(&h->pf.c, sizeof(double) * syms) && grab(&h->pf.tt, sizeof(float) * syms) && grab(&h->pf.xs, sizeof(double) * syms) &&
+                       grab(&h->pf.tile, sizeof(psk::PfTile) * cnt) && grab(&h->pf.blk, sizeof(psk::PfBlock) * (syms / 128u + 1u)) &&
+                       grab(&h->pf.walk, sizeof(psk::PfWalk) * (syms / 128u + 1u));
+            if (got && !h->pf.chan) {
+                got = grab(&h->pf.chan, sizeof(psk::PfChan) * h->nch) && hipMemset(h->pf.chan, 0, sizeof(psk::PfChan) * h->nch) == hipSuccess &&
+                      hipHostMalloc((void **)&h->pf.hint, 64) == hipSuccess;
+                if (got)
+                    *h->pf.hint = 0u;
             }
-            h->tile_cap = cnt;
-            h->tile_sym_cap = syms;
+            if (!got) {
+                (void)hipGetLastError();
+                for (uint32_t i = 0; i < nch; i++) plans[i].lf_flags &= ~(uint32_t)(psk::PLAN_TILED | psk::PLAN_PFIT);
+                for (auto &row : tiled_SH)
+                    for (bool &t : row) t = false;
+                tile_syms = 0;
+            } else {
+                h->tile_cap = cnt;
+                h->tile_sym_cap = syms;
+            }
         }
+    }
+    if (tile_syms) {
         if (!h->tile_ev)
             PSK_HIP(hipEventCreateWithFlags(&h->tile_ev, hipEventDisableTiming));
         // second round of the parallel fit: for the next 16 tiled calls after one whose first guess of the unwrap counts
