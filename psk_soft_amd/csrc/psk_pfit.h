@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void pf_ydiff_kernel(const ChanPlan *__restrict
     const float *y_row = sc.y + g.off;
     const float *yv = yvs + (size_t)(ch0 + bi) * fit_cap;
     double *S_row = sc.S + g.off;
-    double run = 0.0;
+    double run = 0.0, dlast = 0.0;
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
         const float2 y = *reinterpret_cast<const float2 *>(y_row + i0);
@@ -216,9 +216,14 @@ __global__ __launch_bounds__(64) void pf_ydiff_kernel(const ChanPlan *__restrict
         const double a0 = (run + wave_up1(incl, 0.0)) + d0;
         *reinterpret_cast<double2 *>(S_row + i0) = make_double2(a0, a0 + d1);
         run += read_lane(incl, 63);
+        const int rem = g.n_out - c * kB;
+        const int last = (rem < kB ? rem : kB) - 1;
+        dlast = read_lane((last & 1) ? a0 + d1 : a0, last >> 1);
     }
-    if (g.lane == 0)
+    if (g.lane == 0) {
         sc.tile[g.tbase + g.tile].dsum = run;
+        sc.tile[g.tbase + g.tile].dlast = dlast;
+    }
 }
 
 // ---- pf_ysum: grid (tiles, channels) ----
@@ -239,11 +244,20 @@ __global__ __launch_bounds__(64) void pf_ysum_kernel(const ChanPlan *__restrict_
     double soff = 0.0;
     for (int j = g.lane; j < g.tile; j += kWave) soff += sc.tile[g.tbase + j].dsum;
     soff = sc.chan[bi].ySum_c + wave_sum_f64(soff);
+    bool bad = false;
+    if (g.tile > 0) {
+        // The certificate runs from position to position; where it passes from one tile's wave to the next it must be
+        // the same number on both sides: the ySum this tile starts from has to be, bit for bit, the one the tile before
+        // ends with (its own offset, summed the same way, plus its last prefix sum).  Equal whenever the sums are exact.
+        double soff_b = 0.0;
+        for (int j = g.lane; j < g.tile - 1; j += kWave) soff_b += sc.tile[g.tbase + j].dsum;
+        soff_b = sc.chan[bi].ySum_c + wave_sum_f64(soff_b);
+        bad = !same_bits(soff_b + sc.tile[g.tbase + g.tile - 1].dlast, soff);
+    }
     const float xd = p.lf_xdelta;
     const float sizef = (float)(p.lf_n - 1u);  // (float)yvals.size() before the push, :78
     double S_before = soff;  // ySum after the symbol in front of the block
     double xrun = 0.0;
-    bool bad = false;
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
         const bool v0 = i0 < g.n_out, v1 = i0 + 1 < g.n_out;
@@ -645,6 +659,9 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
             *reinterpret_cast<double2 *>(xs_row + i0) = make_double2(xs[0], xs[1]);
         }
         if (!pf_x_ok(s_c, valid, cc, tt, xs))
+            bad = true;
+        // (... and from block to block: the sum the walker carried into the next block is this block's last one, bit for bit)
+        if (c + 1 < g.n_blocks && !same_bits(read_lane(xs[1], 63), rec[1].s_in))
             bad = true;
         const double2 Sv = *reinterpret_cast<const double2 *>(S_row + i0);
         float m_;

@@ -92,6 +92,7 @@ struct PfTile {  // per tile
     int jsum;     // numWraps increments of the tile
     int pad;
     double dsum;  // y[t] - y[t-n] over the tile
+    double dlast; // the tile's prefix sum of those at its last valid position (what pf_ysum turns into the tile's last ySum)
     double xsum;  // term - c over the tile (plain double: only predicts the binade)
 };
 struct PfBlock {  // per 128-symbol block: what pf_xblock prepares for the walker
