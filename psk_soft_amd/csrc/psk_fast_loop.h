@@ -172,62 +172,58 @@ PSK_DEV float2 select_sample(const float2 (&x)[S], int k)
 }
 
 // loads the two symbols at positions 2*lane, 2*lane+1 of "new-symbol block" cblk:
-// tau = kB*cblk + s + A - 1; symbols outside [tau_lo, tau_hi] are zero-filled
+// tau = kB*cblk + s + A - 1; symbols outside [tau_lo, tau_hi] are zero-filled.
+//
+// No lane takes a branch of its own here.  The block is either "steady" -- every symbol wanted and in the packet, a
+// wave-uniform test in scalar arithmetic -- and loaded with 16-byte loads from one base address, or it is one of the
+// few blocks of a call that are not (the first: the carried samples end and the packet begins somewhere inside; the
+// last: partial; the window rebuilds of the prologue) and every lane loads sample by sample, picking buffer and
+// address with selects and zeroing what is not wanted with selects.  An earlier version let each lane choose among
+// three paths (packet / carried samples / the symbol that straddles both) and return early where nothing was wanted:
+// correct as written, but in the instantiations that spill a thousand registers (samplesPerBaud 30 with four blocks
+// of history: 1431 spills) the build of it read one of a symbol's samples as zero in partial blocks -- wrong timing
+// picks in the last block of a call (found by the randomised comparison, rounds 129 and 148 of seed 20261004; the
+// wrong tail block of round 1's <11,4,true> has the same signature).  With uniform control flow the compiler has no
+// lane masks to carry spilled registers across.
+template <int S>
+PSK_DEV void load_symbol_any(const XView &X, uint64_t tau, bool wanted, float2 (&x)[S])
+{
+    const uint64_t j0 = tau * (uint64_t)S;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const uint64_t j = j0 + (uint64_t)k;
+        const f2g *p = j < X.L0 ? X.ring + j : X.in + (j - X.L0);  // (a select of two addresses)
+        const f2g v = *mem_ptr<packet_global(S)>(p);
+        x[k] = make_float2(wanted ? v.x : 0.0f, wanted ? v.y : 0.0f);
+    }
+}
 template <int S>
 PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long tau_lo, long long tau_hi, int lane,
                         float2 (&x)[kR][S])
 {
-    if constexpr (kR == 2 && S < 16) {  // (samplesPerBaud 16 measured 6 % slower with it: registers)
-        // the steady state, decided with scalar arithmetic: every symbol of the block is wanted and sits in
-        // the packet.  One wave-uniform base address plus a per-lane offset that does not change from
-        // block to block -- no per-lane 64-bit address arithmetic, validity tests or exec juggling in
-        // front of the loads.
-        const long long tau_first = cblk * kB + (long long)A - 1;  // symbol of lane 0, r = 0
-        if (tau_first >= tau_lo && tau_first + (kB - 1) <= tau_hi && tau_first >= 0 &&
-            (uint64_t)tau_first * (uint64_t)S >= (uint64_t)X.L0) {
-            const f2g *base = X.in + ((uint64_t)tau_first * (uint64_t)S - (uint64_t)X.L0);
-            const typename F4Ptr<packet_global(S)>::type q =
-                (typename F4Ptr<packet_global(S)>::type)base + (uint32_t)lane * (uint32_t)S;
-            f4g t[S];
+    static_assert(kR == 2, "a lane's two symbols are one run of 2*S samples");
+    const long long tau_first = cblk * kB + (long long)A - 1;  // symbol of lane 0, r = 0
+    if (tau_first >= tau_lo && tau_first + (kB - 1) <= tau_hi && tau_first >= 0 &&
+        (uint64_t)tau_first * (uint64_t)S >= (uint64_t)X.L0) {
+        // steady: one wave-uniform base address plus a per-lane offset that does not change from block to block; a lane's
+        // two symbols are contiguous and 16*S bytes long: S 16-byte loads (at 8-byte alignment, which gfx950 global
+        // loads allow), whatever the parity of S
+        const f2g *base = X.in + ((uint64_t)tau_first * (uint64_t)S - (uint64_t)X.L0);
+        const typename F4Ptr<packet_global(S)>::type q =
+            (typename F4Ptr<packet_global(S)>::type)base + (uint32_t)lane * (uint32_t)S;
 #pragma unroll
-            for (int k = 0; k < S; k++) t[k] = q[k];
-#pragma unroll
-            for (int e = 0; e < 2 * S; e++)  // sample e of the lane's 2*S: half e & 1 of load e / 2
-                x[e / S][e % S] = (e & 1) ? make_float2(t[e / 2].z, t[e / 2].w) : make_float2(t[e / 2].x, t[e / 2].y);
-            return;
+        for (int k = 0; k < S; k++) {
+            const f4g t = q[k];
+            x[(2 * k) / S][(2 * k) % S] = make_float2(t.x, t.y);
+            x[(2 * k + 1) / S][(2 * k + 1) % S] = make_float2(t.z, t.w);
         }
-    }
-    if constexpr (kR == 2 && S < 16) {
-        // odd samplesPerBaud: one symbol is an odd number of 8-byte samples, but a lane's TWO symbols are
-        // contiguous and 16*S bytes long: S 16-byte loads (at 8-byte alignment, which gfx950 global loads
-        // allow) instead of 2*S 8-byte ones, whenever both symbols are wanted and sit in the same buffer
-        const long long tau0 = cblk * kB + 2 * lane + (long long)A - 1;
-        const uint64_t j0 = (uint64_t)(tau0 > 0 ? tau0 : 0) * (uint64_t)S;
-        const bool both = tau0 >= tau_lo && tau0 + 1 <= tau_hi;
-        const bool in_pkt = j0 >= X.L0, in_ring = j0 + 2 * S <= X.L0;
-        if (both && (in_pkt || in_ring)) {
-            const typename F4Ptr<packet_global(S)>::type q =
-                (typename F4Ptr<packet_global(S)>::type)(in_pkt ? X.in + (j0 - X.L0) : X.ring + j0);
-            float2 flat[2 * S];
-#pragma unroll
-            for (int k = 0; k < S; k++) {
-                const f4g t = q[k];
-                flat[2 * k] = make_float2(t.x, t.y);
-                flat[2 * k + 1] = make_float2(t.z, t.w);
-            }
-#pragma unroll
-            for (int k = 0; k < S; k++) {
-                x[0][k] = flat[k];
-                x[1][k] = flat[S + k];
-            }
-            return;
-        }
+        return;
     }
 #pragma unroll
     for (int r = 0; r < kR; r++) {
         const long long tau = cblk * kB + 2 * lane + r + (long long)A - 1;
         const bool ok = tau >= tau_lo && tau <= tau_hi;
-        load_symbol<S>(X, (uint64_t)(ok ? tau : 0), ok, x[r]);
+        load_symbol_any<S>(X, (uint64_t)(ok ? tau : 0), ok, x[r]);  // (symbol 0 exists in every call that emits)
     }
 }
 

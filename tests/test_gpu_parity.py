@@ -413,6 +413,31 @@ def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod):
     h.close()
 
 
+def test_partial_last_block_wide_symbols_s30(oracle_mod):
+    """Two cases of the randomised comparison (tools/fuzz_gpu.py seed 20261004, rounds 129 and 148: channels 154 and
+    18; the fixtures are the tails of their streams): samplesPerBaud 30, numAvg 400, a rectangular pulse in noise -- the
+    30 timing phases within 1e-4 of each other, so the exact-timing instantiation <30, 4, true> (512 registers, 1431
+    spills) decides; the call ends in a partial block.  The build of the time picked phase 9 where 13 had the larger
+    sum by 5e-4, at three positions of that block: one sample of a symbol read as zero.  Its load path let every lane
+    choose its own branch (packet / carried samples / nothing wanted); load_block now has none of that
+    (psk_fast_loop.h), and the wrong tail block of round 1 had the same signature."""
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases")
+    for name, M, n in (("s30_a400_tail_a.npy", 4, 1921), ("s30_a400_tail_b.npy", 8, 200)):
+        sig = np.load(os.path.join(here, name))
+        props = dict(samplesPerBaud=30, constelationSize=M, numAvg=400, phaseAvg=n)
+        ref = oracle_run(oracle_mod, sig, props)
+        assert ref["index"].size % 128 != 0
+        h = _handle(1, max_window_samples=30 * 400 + 64, max_phase_avg=2048)
+        h.configure(0, [props])
+        got = run_gpu(h, 0, sig, 0.01)
+        st = h.stats()
+        assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
+        assert_parity(got, ref, name)
+        h.close()
+
+
 def test_random_configuration_sweep(oracle_mod):
     """256 channels with random (samplesPerBaud, numAvg, M, phaseAvg, diff), random noise level
     and ragged packetisation, three calls each, every stream against the oracle: a broad net for
