@@ -226,6 +226,11 @@ struct psk_soft_handle {
     psk::ChanPlan *h_plans[kPlanSlots] = {};
     psk::ChanPlan *d_plans[kPlanSlots] = {};
     hipEvent_t ev[kPlanSlots] = {};
+    // the plans of a call are uploaded on a stream of their own, so that the copy runs under the kernels of the call before
+    // instead of behind them (20 us of a 4096-channel call); the caller's stream waits for ev_up of the slot
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up[kPlanSlots] = {};
+    int opt_up_stream = 1;  // PSK_SOFT_PLAN_STREAM=0 (environment): upload on the caller's stream (A/B runs)
     bool ev_used[kPlanSlots] = {};
     int slot = 0;
     bool opt_qpsk_sign_map = false;  // PSK_SOFT_OPT_QPSK_SIGN_BITMAP
@@ -345,7 +350,13 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
                 return bail("hipMalloc plans", e2);
             if ((e2 = hipEventCreateWithFlags(&h->ev[s], hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e2);
+            if ((e2 = hipEventCreateWithFlags(&h->ev_up[s], hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate", e2);
         }
+        if ((e2 = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", e2);
+        if (const char *e = std::getenv("PSK_SOFT_PLAN_STREAM"))
+            h->opt_up_stream = std::atoi(e) != 0;
     }
     *out = h;
     return PSK_SOFT_OK;
@@ -363,6 +374,7 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
             if (h->h_plans[s]) (void)hipHostFree(h->h_plans[s]);
             if (h->d_plans[s]) (void)hipFree(h->d_plans[s]);
             if (h->ev[s]) (void)hipEventDestroy(h->ev[s]);
+            if (h->ev_up[s]) (void)hipEventDestroy(h->ev_up[s]);
         }
         if (h->d_state) (void)hipFree(h->d_state);
         if (h->d_ring) (void)hipFree(h->d_ring);
@@ -390,6 +402,10 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
             if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
         }
         if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
+        if (h->up_stream) {
+            (void)hipStreamSynchronize(h->up_stream);
+            (void)hipStreamDestroy(h->up_stream);
+        }
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -668,8 +684,16 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
             PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
     }
-    PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
-                           hipMemcpyHostToDevice, stream));
+    if (h->opt_up_stream) {
+        // (the slot's previous user has finished -- waited for above --, nothing else reads or writes d_plans[slot])
+        PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
+                               hipMemcpyHostToDevice, h->up_stream));
+        PSK_HIP(hipEventRecord(h->ev_up[slot], h->up_stream));
+        PSK_HIP(hipStreamWaitEvent(stream, h->ev_up[slot], 0));
+    } else {
+        PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
+                               hipMemcpyHostToDevice, stream));
+    }
     // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
     // the energy ring is dynamic too and every byte of LDS counts towards residency)
     auto ring_floats = [](uint32_t n_max, uint32_t at_least) {

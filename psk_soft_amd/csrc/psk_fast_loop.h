@@ -1373,10 +1373,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             const bool miss = valid[r] && (pkk[r] != bestK[r]);
-            if (miss) {
-                float2 g = x_at(X, (uint64_t)(i0 + r) * S + (uint64_t)bestK[r]);
-                px[r] = g.x;
-                py[r] = g.y;
+            if (vote_any(miss)) {  // (wave-uniform, like every branch around loads here: see load_block)
+                const uint64_t j = miss ? (uint64_t)(i0 + r) * S + (uint64_t)bestK[r] : 0ull;  // (sample 0 exists)
+                const f2g *q = j < X.L0 ? X.ring + j : X.in + (j - X.L0);
+                const f2g g = *mem_ptr<packet_global(S)>(q);
+                px[r] = miss ? g.x : px[r];
+                py[r] = miss ? g.y : py[r];
             }
             s[r].re = px[r];
             s[r].im = py[r];
