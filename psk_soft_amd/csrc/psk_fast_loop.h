@@ -579,7 +579,7 @@ template <bool WARM, bool WIDE>
 PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, float xavg_s, const FitKnown &fk,
                       const bool (&valid)[kR], const float (&raw)[kR], const FastCarry &cy,
                       float *yring, uint32_t ymask, float (&y)[kR], float (&est)[kR], double (&ySum_l)[kR], double (&xySum_l)[kR],
-                      int lane_last, int r_last, float &den_last, float &xavg_last, bool cheap, int &rejected)
+                      int lane_last, int r_last, float &den_last, float &xavg_last, bool cheap, int &rejected, float &m_last)
 {
     uint32_t before[kR];
     bool steady[kR];
@@ -670,6 +670,7 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
         if (cheap)
             rej |= 2;
         rejected = rej;
+        float m_l[kR];  // LinearFit::m of the fits (a by-product: the block's last one predicts the next block's estimates)
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             float m_ = 0.0f, b_;
@@ -680,7 +681,9 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             } else {  // :164-171, a single point: b = yvals.back()
                 est[r] = y[r];
             }
+            m_l[r] = m_;
         }
+        m_last = r_last ? m_l[1] : m_l[0];
         const float est_prev0 = wave_up1(est[1], cy.est);
         {
             // round((est_prev - raw)/2pi) == w  <=>  |est_prev - (raw + 2 pi w)| < pi; with the
@@ -891,14 +894,15 @@ PSK_DEV void fit_stage(int c, int lane, uint32_t n, float xd, float den_s, float
     double ySum_l[kR], xySum_l[kR];
     float den_last = den_s, xavg_last = xavg_s;
     int pass, rejected = 0;
+    float m_lane = 0.0f;  // (per lane) slope of the lane's last fit
     const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
     const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
     if (!warm) {
         pass = fit_block<false, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                                lane_last, r_last, den_last, xavg_last, cheap, rejected);
+                                lane_last, r_last, den_last, xavg_last, cheap, rejected, m_lane);
     } else {
         pass = fit_block<true, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,
-                               lane_last, r_last, den_last, xavg_last, cheap, rejected);
+                               lane_last, r_last, den_last, xavg_last, cheap, rejected, m_lane);
     }
 #ifdef PSK_ABL_NOCHAIN  /* (ablation builds only: what the chain costs) */
     rejected = 0;
@@ -964,9 +968,7 @@ PSK_DEV void fit_stage(int c, int lane, uint32_t n, float xd, float den_s, float
         {
             // slope of the line just fitted, per symbol (LinearFit::m * xdelta, steady-state
             // constants): only a hint for the next block's speculation, so approximate is fine
-            float m_hint;
-            (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
-            m_hint *= xd;
+            const float m_hint = read_lane(m_lane, lane_last) * xd;  // (of the wave-parallel candidates where the chain ran: a hint)
             cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
         }
         const uint32_t pts_last = (q0 + (uint32_t)nvalid - 1 >= n) ? n : q0 + (uint32_t)nvalid;
