@@ -214,14 +214,23 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
         float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len, hipStream_t stream
 
 // Dynamic LDS beyond the 64 KiB a kernel gets by default (a phase ring for phaseAvg in the thousands) has to be asked
-// for, once per kernel and size; `granted` is the kernel's own record of what it has asked for so far.
-inline hipError_t lds_grant(const void *kernel, size_t bytes, size_t &granted)
+// for, per kernel, device and size; LdsGrant is the kernel's own record of what it has asked for so far.
+struct LdsGrant {
+    size_t bytes[32] = {};  // per device
+};
+inline hipError_t lds_grant(const void *kernel, size_t bytes, LdsGrant &granted)
 {
-    if (bytes <= 65536 || bytes <= granted)
+    if (bytes <= 65536)
+        return hipSuccess;
+    int dev = 0;
+    if (const hipError_t e = hipGetDevice(&dev))
+        return e;
+    size_t &have = granted.bytes[dev & 31];
+    if (bytes <= have)
         return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess)
-        granted = bytes;
+        have = bytes;
     return e;
 }
 
@@ -231,7 +240,7 @@ hipError_t launch_fast_inst(PSK_FAST_ARGS)
     if (!nch)
         return hipSuccess;
     const size_t lds_bytes = sizeof(float) * ((size_t)y_len + (ering_dynamic(SV) ? (size_t)SV * r_len : 0));
-    static size_t granted = 0;
+    static LdsGrant granted;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_fast_kernel<SV, HV, EXACT>), lds_bytes, granted))
         return e;
     hipLaunchKernelGGL((psk_fast_kernel<SV, HV, EXACT>), dim3(nch), dim3(kWave), lds_bytes, stream, plans, list, ch0, states,

@@ -320,7 +320,7 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
 {
     if (!nch)
         return hipSuccess;
-    static size_t granted = 0;
+    static LdsGrant granted;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_tile_fit_kernel), sizeof(float) * (size_t)y_len, granted))
         return e;
     hipLaunchKernelGGL(psk_tile_fit_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
@@ -337,7 +337,7 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
     if (!nch || !max_tiles)
         return hipSuccess;
     const dim3 grid(max_tiles, nch), wave(kWave);
-    static size_t granted_b = 0, granted_c = 0;
+    static LdsGrant granted_b, granted_c;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_begin_kernel), sizeof(float) * (size_t)y_len, granted_b))
         return e;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_commit_kernel), sizeof(float) * (size_t)y_len, granted_c))
