@@ -241,3 +241,22 @@ def test_tiled_device_batch_auto(oracle_mod):
     from tests.test_gpu_parity import _device_batch
 
     _device_batch(oracle_mod, 4, 8, 100, 50, 64, [1 << 16, (1 << 16) - 24], (0, 1, 31, 63), expect_tiled=64)
+
+
+@pytest.mark.parametrize("name", [
+    "test_mixed_batch_parity", "test_edge_packets", "test_tie_heavy_signal_takes_the_exact_timing_path",
+    "test_host_sized_energy_ring", "test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel", "test_deep_fit_windows",
+    "test_random_configuration_sweep", "test_exactness_guard_hands_over", "test_non_finite_samples_stay_on_the_wave_scan_kernels",
+    "test_noisy_unwrap_fixed_point", "test_state_roundtrip", "test_property_changes_mid_stream",
+    "test_minimum_alignment_of_packets_and_outputs", "test_large_carrier_offset_in_one_call",
+    "test_silent_streams_stay_on_the_fast_path", "test_zero_copy_from_pinned_host_memory",
+])
+def test_parity_suite_through_the_tiles(oracle_mod, monkeypatch, name):
+    """The edge cases of tests/test_gpu_parity.py once more with every call that has kernels for it cut along time and the
+    parallel fit's second round always enqueued (the environment switches new handles read): property changes and resets
+    between calls, ragged and empty packets, ties, non-finite samples, state export / import, deep fit windows."""
+    import tests.test_gpu_parity as tp
+
+    monkeypatch.setenv("PSK_SOFT_TIME_TILED", "2")
+    monkeypatch.setenv("PSK_SOFT_PARALLEL_FIT", "2")
+    getattr(tp, name)(oracle_mod)
