@@ -535,9 +535,6 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
         int slow_mine = 0;
         int start = 0;
         while (start < nb) {
-#ifdef PSK_PF_DEBUG
-            slow_blocks += 1u << 12;
-#endif
             // parity the run starts with: carried, or from the sum where the scale is new
             const int fl_s = __builtin_amdgcn_readlane(rec.flags, start);
             if (par < 0 || !(fl_s & 4))
@@ -570,15 +567,6 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
             const bool enter_ok = usable && rec.a < s_before && s_before < rec.b && (lane == start || (rec.flags & 4));
             const unsigned long long stops = vote_mask(inside && !enter_ok);
             const int f = stops ? (int)__builtin_ctzll(stops) : nb;  // first block that cannot be entered in this run
-#ifdef PSK_PF_DEBUG
-            if (b0 == 0 && start < 12) {
-                const int flf = __builtin_amdgcn_readlane(rec.flags, f < nb ? f : 0);
-                const double af = read_lane(rec.a, f < nb ? f : 0), bf = read_lane(rec.b, f < nb ? f : 0), sb = read_lane(s_before, f < nb ? f : 0);
-                const double d0f = read_lane(dS0, f < nb ? f : 0);
-                if (lane == 0)
-                    printf("start %d f %d stops %llx flags_f %d a %.17g b %.17g s_before_f %.17g s_c %.17g dS0_f %.17g par %d\n", start, f, stops, flf, af, bf, sb, s_c, d0f, par);
-            }
-#endif
             if (lane >= start && lane < f)
                 s_in_mine = s_before;
             if (f > start) {
