@@ -24,8 +24,9 @@
 //   pf_verify   per block, with its true carried s: the 128 sums, statements :72 / :78 re-run on every position's
 //               predecessor and compared bit for bit; the estimates; numWraps re-derived from the predecessor's
 //               estimate exactly as :477 does and compared with the guess
-//   pf_commit   nothing failed anywhere: by induction from the carried state every value IS the reference's; end-of-call
-//               wrap and state commit as in the other kernels.
+//   (commit)    nothing failed anywhere: by induction from the carried state every value IS the reference's; the fit kernel
+//               of the time-tiled path, launched behind in any case, ends the call from these results (pf_commit in
+//               psk_tile.hip: end-of-call wrap and state commit as in the other kernels) instead of walking it.
 //
 // A second round (pf_retry, then pf_y ... pf_verify again) takes the calls whose unwrap counts, and nothing else, failed the
 // first: its guess is what the first round's estimates -- off by a few hundredths of a radian around the wrong counts --

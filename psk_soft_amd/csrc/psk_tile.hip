@@ -49,13 +49,77 @@ PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int l
     return refuse;
 }
 
+// ---- the parallel fit verified (psk_pfit.h): end of the call from its results ----
+PSK_DEV void pf_commit(const ChanPlan &p, uint32_t bi, uint32_t ch, ChanState *st, float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap,
+                       float *yring, uint32_t ymask, TileInfo *ti, int n_tiles, int exact_blocks, const float2 *t_s, const float *t_est,
+                       const PfScratch &sc, int lane)
+{
+    const int n_out = (int)p.n_out;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
+    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
+    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
+    float *yv = yvs + (size_t)ch * fit_cap;
+    XView X;
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
+    X.L0 = p.ring_len0;
+
+    // the fit window at the end of the call, where the epilogue looks for it: position j of the window at ring index
+    // q - n + j, q = values pushed so far
+    const int n = (int)p.lf_n;
+    const float *y_row = sc.y + p.tile_off;
+    const uint32_t q_end = p.lf_len0 + (uint32_t)n_out;
+    for (int j = lane; j < n; j += kWave) {
+        const int t = n_out - n + j;
+        yring[(q_end - (uint32_t)n + (uint32_t)j) & ymask] = t >= 0 ? y_row[t] : yv[(p.lf_head + (uint32_t)(t + n)) % fit_cap];
+    }
+    wave_lds_fence();
+    FastCarry cy;
+    cy.ySum = sc.S[p.tile_off + (uint64_t)(n_out - 1)];
+    cy.xySum = sc.xs[p.tile_off + (uint64_t)(n_out - 1)];
+    cy.est = t_est[p.tile_off + (uint64_t)(n_out - 1)];
+    cy.last_re = st->last_re;
+    cy.last_im = st->last_im;
+    const float last0_re = cy.last_re, last0_im = cy.last_im;
+    cy.den = st->lf_den;
+    cy.xavg = st->lf_xavg;
+    fit_denominator(p.lf_xdelta, p.lf_n, cy.den, cy.xavg);
+    {
+        const FitKnown fk = fit_known(p.lf_xdelta, p.lf_n, cy.den, cy.xavg);
+        float m_hint;
+        (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
+        m_hint *= p.lf_xdelta;
+        cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
+    }
+    cy.m = cy.b = 0.0f;
+    cy.q = q_end;
+    cy.last_k = ti[n_tiles - 1].last_k;
+    cy.stat_blocks = (uint32_t)n_blocks;
+    cy.stat_extra = 0;
+    cy.stat_exact_blocks = (uint32_t)exact_blocks;
+    cy.stat_chain = sc.chan[bi].slow_blocks;
+    if (p.diff) {
+        const float2 l = t_s[p.tile_off + (uint64_t)(n_out - 1)];
+        cy.last_re = l.x;
+        cy.last_im = l.y;
+    }
+    if (lane == 0) {
+        ti[0].last0_re = last0_re;
+        ti[0].last0_im = last0_im;
+        sc.chan[bi].done = 1u;
+    }
+    call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
+    if (lane == 0)
+        st->stat_pfit = 1u | (sc.chan[bi].retry ? 0x100u : 0u);
+}
+
 // ---- fit: one wave per channel ----
 __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                           ChanState *__restrict__ states, float2 *__restrict__ rings, uint32_t ring_cap,
                                                           float *__restrict__ yvs, uint32_t fit_cap, uint32_t y_len,
                                                           TileInfo *__restrict__ tiles, const float *__restrict__ t_raw,
-                                                          const float2 *__restrict__ t_s, float *__restrict__ t_est,
-                                                          const PfChan *__restrict__ pf_chan, uint32_t *__restrict__ pf_hint)
+                                                          const float2 *__restrict__ t_s, float *__restrict__ t_est, PfScratch sc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float *const yring = lds_dyn;
@@ -65,8 +129,6 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     const ChanPlan &p = plans[bi];
     if (!tile_plan_mine(p))
         return;
-    if ((p.lf_flags & PLAN_PFIT) && pf_chan[bi].done)
-        return;  // the parallel fit (psk_pfit.h) carried this call and committed it
     const uint32_t ch = ch0 + bi;
     ChanState *st = &states[ch];
     const int n_out = (int)p.n_out;
@@ -79,6 +141,11 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     if (refuse) {
         if (lane == 0)
             st->guard = 1u;
+        return;
+    }
+    if ((p.lf_flags & PLAN_PFIT) && sc.chan[bi].fail == 0u) {
+        // the parallel fit (psk_pfit.h) carried this call and every position verified: commit from its results
+        pf_commit(p, bi, ch, st, rings, ring_cap, yvs, fit_cap, yring, ymask, ti, n_tiles, exact_blocks, t_s, t_est, sc, lane);
         return;
     }
 
@@ -140,9 +207,9 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     }
     call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
     if ((p.lf_flags & PLAN_PFIT) && lane == 0) {
-        st->stat_pfit = pf_chan[bi].fail << 1;  // (statistics: why the parallel fit left the call to this kernel)
-        if (pf_chan[bi].fail & kPfFailUnwrap)
-            *pf_hint = 1u;
+        st->stat_pfit = sc.chan[bi].fail << 1;  // (statistics: why the parallel fit left the call to this kernel)
+        if (sc.chan[bi].fail & kPfFailUnwrap)
+            *sc.hint = 1u;
     }
 }
 
@@ -163,89 +230,6 @@ __global__ __launch_bounds__(64) void pf_begin_kernel(const ChanPlan *__restrict
         sc.chan[bi].ySum_c = cy.ySum;
         sc.chan[bi].xySum_c = cy.xySum;
     }
-}
-
-// ---- pf_commit: one wave per channel (psk_pfit.h) ----
-__global__ __launch_bounds__(64) void pf_commit_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                       ChanState *__restrict__ states, float2 *__restrict__ rings, uint32_t ring_cap,
-                                                       float *__restrict__ yvs, uint32_t fit_cap, uint32_t y_len,
-                                                       TileInfo *__restrict__ tiles, const float2 *__restrict__ t_s,
-                                                       const float *__restrict__ t_est, PfScratch sc)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    float *const yring = lds_dyn;
-    const uint32_t ymask = y_len - 1u;
-    const int lane = threadIdx.x & 63;
-    const uint32_t bi = list[blockIdx.x];
-    const ChanPlan &p = plans[bi];
-    if (!pf_mine(p) || sc.chan[bi].fail)
-        return;
-    const uint32_t ch = ch0 + bi;
-    ChanState *st = &states[ch];
-    const int n_out = (int)p.n_out;
-    const int n_blocks = (n_out + kB - 1) / kB;
-    const int n_tiles = (n_blocks + (int)p.tile_blocks - 1) / (int)p.tile_blocks;
-    TileInfo *const ti = tiles + p.tile_base;
-    int exact_blocks = 0;
-    if (tile_fold(p, ti, n_tiles, lane, exact_blocks))
-        return;  // (the fit kernel behind hands the call over)
-
-    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
-    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
-    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
-    float *yv = yvs + (size_t)ch * fit_cap;
-    XView X;
-    X.ring = reinterpret_cast<const f2g *>(ring_src);
-    X.in = reinterpret_cast<const f2g *>(p.in);
-    X.L0 = p.ring_len0;
-
-    // the fit window at the end of the call, where the epilogue looks for it: position j of the window at ring index
-    // q - n + j, q = values pushed so far
-    const int n = (int)p.lf_n;
-    const float *y_row = sc.y + p.tile_off;
-    const uint32_t q_end = p.lf_len0 + (uint32_t)n_out;
-    for (int j = lane; j < n; j += kWave) {
-        const int t = n_out - n + j;
-        yring[(q_end - (uint32_t)n + (uint32_t)j) & ymask] = t >= 0 ? y_row[t] : yv[(p.lf_head + (uint32_t)(t + n)) % fit_cap];
-    }
-    wave_lds_fence();
-    FastCarry cy;
-    cy.ySum = sc.S[p.tile_off + (uint64_t)(n_out - 1)];
-    cy.xySum = sc.xs[p.tile_off + (uint64_t)(n_out - 1)];
-    cy.est = t_est[p.tile_off + (uint64_t)(n_out - 1)];
-    cy.last_re = st->last_re;
-    cy.last_im = st->last_im;
-    const float last0_re = cy.last_re, last0_im = cy.last_im;
-    cy.den = st->lf_den;
-    cy.xavg = st->lf_xavg;
-    fit_denominator(p.lf_xdelta, p.lf_n, cy.den, cy.xavg);
-    {
-        const FitKnown fk = fit_known(p.lf_xdelta, p.lf_n, cy.den, cy.xavg);
-        float m_hint;
-        (void)fit_value_known(cy.ySum, cy.xySum, fk, m_hint);
-        m_hint *= p.lf_xdelta;
-        cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
-    }
-    cy.m = cy.b = 0.0f;
-    cy.q = q_end;
-    cy.last_k = ti[n_tiles - 1].last_k;
-    cy.stat_blocks = (uint32_t)n_blocks;
-    cy.stat_extra = 0;
-    cy.stat_exact_blocks = (uint32_t)exact_blocks;
-    cy.stat_chain = sc.chan[bi].slow_blocks;
-    if (p.diff) {
-        const float2 l = t_s[p.tile_off + (uint64_t)(n_out - 1)];
-        cy.last_re = l.x;
-        cy.last_im = l.y;
-    }
-    if (lane == 0) {
-        ti[0].last0_re = last0_re;
-        ti[0].last0_im = last0_im;
-        sc.chan[bi].done = 1u;
-    }
-    call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
-    if (lane == 0)
-        st->stat_pfit = 1u | (sc.chan[bi].retry ? 0x100u : 0u);
 }
 
 // ---- back: grid (tiles, channels of the launch) ----
@@ -324,7 +308,7 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&psk_tile_fit_kernel), sizeof(float) * (size_t)y_len, granted))
         return e;
     hipLaunchKernelGGL(psk_tile_fit_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
-                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, sc.chan, sc.hint);
+                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, sc);
     return hipGetLastError();
 }
 
@@ -337,10 +321,8 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
     if (!nch || !max_tiles)
         return hipSuccess;
     const dim3 grid(max_tiles, nch), wave(kWave);
-    static LdsGrant granted_b, granted_c;
+    static LdsGrant granted_b;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_begin_kernel), sizeof(float) * (size_t)y_len, granted_b))
-        return e;
-    if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_commit_kernel), sizeof(float) * (size_t)y_len, granted_c))
         return e;
     hipLaunchKernelGGL(pf_begin_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, yvs, fit_cap, y_len, sc);
     hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc);
@@ -354,8 +336,6 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
         hipLaunchKernelGGL(pf_xwalk_kernel, dim3(nch), wave, 0, stream, plans, list, sc.blk, sc, round);
         hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, t_est, sc, round);
     }
-    hipLaunchKernelGGL(pf_commit_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings, ring_cap,
-                       yvs, fit_cap, y_len, tiles, t_s, t_est, sc);
     return hipGetLastError();
 }
 
