@@ -762,7 +762,9 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                               h->d_tiles, h->d_ts, h->d_test, st));
             }
-            for (int exact = 0; exact <= 1; exact++)  // (the exact tier only works on the calls the screened tier left)
+            // (the exact tier only works on the calls the tier in front of it left; behind the time-tiled kernels, whose front
+            // stage IS the screened timing, it is the exact tier that picks up what they hand over)
+            for (int exact = tiled_SH[S][H] ? 1 : 0; exact <= 1; exact++)
                 PSK_HIP(psk::launch_fast(S, class_H(H), exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
         }
