@@ -71,6 +71,7 @@ struct FastCarry {
     uint32_t chain_streak; // low half: chained blocks in a row; high half: blocks left of the raised priority
     float gap_rel;         // (time-tiled front kernel only) smallest gap / relative bound among the exact re-decisions: a tile
                            // does not know the largest sum of the whole call, the fit kernel compares once it does
+    float emax;            // (time-tiled front kernel only) largest sample energy loaded
     float cap;             // (time-tiled front kernel only) largest window sum anywhere in the call up to which the screening
                            // thresholds this tile used still exceed what the reference's running sums may have drifted by
 };
@@ -1085,7 +1086,7 @@ PSK_DEV void output_stage(const ChanPlan &p, int c, int i0, const bool (&valid)[
 // the caller.  Unwrap, fit and de-rotation happen in the later stages.
 template <int S, int H, bool EXACT, bool FRONT = false>
 PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uint32_t ymask, const ERingT<ering_dynamic(S)> &er, FastCarry &cy,
-                            int c_begin = 0, int c_end = -1, float *t_raw = nullptr, float2 *t_s = nullptr)
+                            int c_begin = 0, int c_end = -1, float *t_raw = nullptr, float2 *t_s = nullptr, float wmax_floor = 0.0f)
 {
 
     const int lane = threadIdx.x & 63;
@@ -1139,6 +1140,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     float wmax_prev = 0.0f;
 #pragma unroll
     for (int k = 0; k < S; k++) wmax_prev = __builtin_fmaxf(wmax_prev, Wf[k]);
+    if constexpr (FRONT)  // (a tile starts from what the channel's last call says its window sums can reach: see ChanState::emax_hint)
+        wmax_prev = __builtin_fmaxf(wmax_prev, wmax_floor);
     float err_c = 2.0f * kU * wmax_prev;
     // rounding-error budget of one screened block, relative to the largest window sum in play:
     // the local roundings of up to 2*(128/A+1) window-loads of energy pass through the scan, plus
@@ -1198,6 +1201,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 float e = norm_f(xn[r][k].x, xn[r][k].y);
                 if (EXACT)
                     guard_track<true>(cy, e);
+                if constexpr (FRONT)
+                    cy.emax = __builtin_fmaxf(cy.emax, e);
                 cur.e[r][k] = e;
             }
             cur.kp[r] = kpred[r];

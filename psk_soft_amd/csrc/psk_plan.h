@@ -84,7 +84,8 @@ struct TileInfo {
     uint32_t last_k;       // timing index of its last symbol (the last tile's is the channel's)
     float cap;             // largest sum of the whole call its screening thresholds allow for (FastCarry::cap)
     float last0_re, last0_im;  // (tile 0, written by the fit kernel) psk_soft_i::last at the start of the call
-    uint32_t pad2[2];
+    float emax;                // largest sample energy the tile loaded
+    uint32_t pad2;
 };
 
 // Bookkeeping of the parallel fit (psk_pfit.h), in the scratch of the call next to the TileInfo records.
@@ -145,6 +146,9 @@ struct ChanState {
     uint32_t last_k;      // timing index of the last emitted symbol (prediction seed of the wave-scan kernel)
     uint32_t stat_exact;  // blocks whose timing argmax needed the exact double-precision pass
     uint32_t stat_chain;  // blocks whose LinearFit sums were redone by the reference-order chain (psk_fast_loop.h)
+    float emax_hint;      // (time-tiled kernels) largest sample energy of the channel's last tiled call: scales the screening
+                          // thresholds of the next one's tiles, which do not know the largest window sum of their call
+    uint32_t pad_state;
     uint32_t stat_pfit;   // bit 0: the call's unwrap and fit were done in parallel along time (psk_pfit.h), bit 8: in the second
                           // round; else 2 * (why not: PfChan::fail)
 };

@@ -6,8 +6,9 @@
 namespace psk {
 
 // What the tiles of the front kernel found, folded over the call: true = the call is not theirs to carry.
-PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int lane, int &exact_blocks_out)
+PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int lane, int &exact_blocks_out, float &emax_out)
 {
+    float emax = 0.0f;
     unsigned umax = 0u, umin1 = 0xFFFFFFFFu, refuse_b = 0u, gap_b = 0x7F800000u, cap_b = 0x7F800000u, wmax_b = 0u;
     int exact_blocks = 0;
     for (int j = lane; j < n_tiles; j += kWave) {
@@ -21,7 +22,9 @@ PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int l
         // (a NaN maximum -- bit pattern above inf's -- stays on top and fails both comparisons below)
         wmax_b = w > wmax_b ? w : wmax_b;
         exact_blocks += (int)t.stat_exact;
+        emax = __builtin_fmaxf(emax, t.emax);
     }
+    emax_out = wave_max_f32(__builtin_fmaxf(emax, 0.0f));
     umax = wave_max_u32(umax);
     umin1 = wave_min_u32(umin1);
     gap_b = wave_min_u32(gap_b);
@@ -32,7 +35,9 @@ PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int l
     {
         const float wmax = __uint_as_float(wmax_b);
         // the screening thresholds of every tile must cover the drift of the reference's sums at the scale of the call
-        if (!(wmax <= __uint_as_float(cap_b)))
+        // (a silent call: every window sum is exactly zero, `wmax` is the denormal the phase-index bits of the screening's
+        // argmax leave behind, thresholds and `cap` are zero -- and the first phase wins there as in the reference)
+        if (!(wmax <= __uint_as_float(cap_b)) && !(wmax < 1.0e-37f))
             refuse = true;
         // an exact re-decision closer than that drift: only the exactness guard (quirk Q8) can vouch for it
         const bool ambiguous = !(__uint_as_float(gap_b) > wmax);
@@ -137,7 +142,10 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     TileInfo *const ti = tiles + p.tile_base;
 
     int exact_blocks = 0;
-    const bool refuse = tile_fold(p, ti, n_tiles, lane, exact_blocks);
+    float emax = 0.0f;
+    const bool refuse = tile_fold(p, ti, n_tiles, lane, exact_blocks, emax);
+    if (lane == 0)
+        st->emax_hint = emax;  // (not part of the reference's state: kept whether or not the call stays here)
     if (refuse) {
         if (lane == 0)
             st->guard = 1u;

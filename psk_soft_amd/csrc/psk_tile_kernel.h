@@ -82,12 +82,18 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
     cy.stat_exact_blocks = 0;
     cy.gap_rel = __builtin_inff();
     cy.cap = __builtin_inff();
-    fast_main_loop<SV, HV, false, true>(p, X, nullptr, 0u, er, cy, c_begin, c_end, t_raw + p.tile_off, t_s + p.tile_off);
+    cy.emax = 0.0f;
+    // a window sum of the call can reach numAvg times its largest sample energy; the last tiled call's stands in for this one's
+    // (a call that outgrows it by four decades is handed over by the fit kernel's fold, TileInfo::cap)
+    const float hint = states[ch].emax_hint;
+    const float wmax_floor = (hint > 0.0f && hint < 3.0e38f) ? hint * (float)p.A * 1.000001f : 0.0f;
+    fast_main_loop<SV, HV, false, true>(p, X, nullptr, 0u, er, cy, c_begin, c_end, t_raw + p.tile_off, t_s + p.tile_off, wmax_floor);
 
     const unsigned umax = wave_max_u32(cy.umax), umin1 = wave_min_u32(cy.umin1);
     // (gap_rel and cap are non-negative or +inf: their bit patterns order like the values)
     const unsigned gap_b = wave_min_u32(__float_as_uint(cy.gap_rel)), cap_b = wave_min_u32(__float_as_uint(cy.cap));
     const bool refuse = __any(cy.refuse);
+    const float emax = wave_max_f32(__builtin_fmaxf(cy.emax, 0.0f));
     if (lane == 0) {
         TileInfo &t = tiles[p.tile_base + blockIdx.x];
         t.umax = umax;
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
         t.stat_exact = cy.stat_exact_blocks;
         t.last_k = cy.last_k;
         t.cap = __uint_as_float(cap_b);
+        t.emax = emax;
     }
 }
 

@@ -952,12 +952,7 @@ def test_silent_streams_stay_on_the_fast_path(oracle_mod):
             got = run_gpu(h, 0, iq, 0.01, 8192)
             st = h.stats()
             assert_parity(got, ref, "silence diff%d %s" % (diff, kind))
-            assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, (st, diff, kind)
-            # (a call cut along time -- test_gpu_tiled.py replays this test that way -- hands a silence-to-signal transition
-            # over: a tile does not know the largest window sum of the call, and it is the exact tier that stands behind it)
-            import os
-
-            assert st["channels_exact_timing"] == 0 or os.environ.get("PSK_SOFT_TIME_TILED") == "2", (st, diff, kind)
+            assert st["channels_fast"] == 1 and st["channels_sequential"] == 0 and st["channels_exact_timing"] == 0, (st, diff, kind)
             h.close()
 
 

@@ -184,6 +184,40 @@ def test_parallel_fit_verifies_or_steps_back(oracle_mod):
         h.close()
 
 
+def test_tiled_bursts_and_gaps(oracle_mod):
+    """A tile does not know the largest window sum of its call, which the screening thresholds scale with: it starts from
+    what the channel's last tiled call says the sums can reach (ChanState::emax_hint).  A stream that goes silent, comes
+    back, or jumps by 60 dB inside a call stays on the tile path from its second call on; same bits."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for kind in ("gap", "burst", "fade", "zeros"):
+        iq = synth_channel(960, 4, 8, 1 << 16).copy()
+        if kind == "gap":
+            iq[2 * 20000 : 2 * 30000] = 0
+        elif kind == "burst":
+            iq[: 2 * 40000] *= 1e-3
+        elif kind == "fade":
+            iq[2 * 40000 :] *= 1e-3
+        else:
+            iq[:] = 0
+        props = dict(samplesPerBaud=8, constelationSize=4, numAvg=100, phaseAvg=50)
+        ref = oracle_run(oracle_mod, iq, props, packet=1 << 14)
+        h = _tiled_handle()
+        h.configure(0, [props])
+        n, tiled = 1 << 14, 0
+        got = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(4):
+            r = h.process_host(0, [dict(data=iq[2 * n * k : 2 * n * (k + 1)], xdelta=0.01, sriChanged=(k == 0))])[0]
+            st = h.stats()
+            assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, (kind, k, st)
+            tiled += st["channels_tiled"]
+            for key in got:
+                got[key].append(r[key])
+        assert tiled == 4, (kind, tiled)
+        assert_parity({key: np.concatenate(v) for key, v in got.items()}, ref, kind)
+        h.close()
+
+
 def test_parallel_fit_second_round(oracle_mod):
     """16 dB: the first guess of the unwrap counts (towards a smoothed carrier trajectory) misses single symbols in
     some calls; the second round, on the counts the first round's estimates give, verifies.  With the round always
