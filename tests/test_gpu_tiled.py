@@ -75,6 +75,31 @@ def test_tiled_matches_long_run(oracle_mod):
     h.close()
 
 
+def test_tiled_largest_call(oracle_mod):
+    """The largest call the wave-scan and time-tiled kernels take: 2^20 symbols out (LinearFit::count reaches 1048576 at the
+    call's last symbol, cpp/psk_soft.cpp:51): 8192 blocks, 4096 tiles, a second call behind it on the carried state."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    S, A = 4, 50
+    n1 = ((1 << 20) + A - 1) * S
+    iq = synth_channel(11, 4, S, n1 + 40000)
+    props = dict(samplesPerBaud=S, constelationSize=4, numAvg=A, phaseAvg=50)
+    o = oracle_mod.OracleComponent()
+    for k, v in props.items():
+        setattr(o, k, v)
+    h = _handle(1, max_packet_complex=n1)
+    h.configure(0, [props])
+    for k, (lo, hi) in enumerate(((0, n1), (n1, n1 + 40000))):
+        g = h.process_host(0, [dict(data=iq[2 * lo : 2 * hi], xdelta=0.01, sriChanged=(k == 0))])[0]
+        r = o.service(iq[2 * lo : 2 * hi], 0.01, sriChanged=(k == 0))
+        st = h.stats()
+        assert st["channels_tiled"] == 1 and st["channels_sequential"] == 0, (k, st)
+        if k == 0:
+            assert r.phase.size == 1 << 20
+        assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "call %d" % k)
+    h.close()
+
+
 def test_tiled_mixed_batch_with_carried_state(oracle_mod):
     """Several window classes in one batch, three calls with ragged cuts: every call starts from the state the call
     before left (sample ring, LinearFit history and sums, differential `last`), tiled and not."""
