@@ -36,6 +36,9 @@ bool tile_front_has(int S, int H);
 hipError_t launch_tile_front(int S, int H, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                              const ChanState *states, const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw,
                              float2 *t_s, PfChan *pf_chan, hipStream_t stream);
+hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+                                 const ChanState *states, const float2 *rings, uint32_t ring_cap, TileInfo *tiles, float *t_raw, float2 *t_s,
+                                 PfChan *pf_chan, hipStream_t stream);
 hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                            uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
                            const float2 *t_s, float *t_est, const PfScratch &sc, hipStream_t stream);
@@ -165,6 +168,9 @@ struct PlanSummary {
     // time-tiled kernels: 128-symbol blocks of the class, in all and of its longest call
     uint64_t blocks_SH[33][17] = {};
     uint32_t max_blocks_SH[33][17] = {};
+    // the window classes without an instantiation (PLAN_ANYFRONT), one launch set for all of them
+    uint32_t cnt_any = 0, max_n_any = 0, max_A_any = 0, max_blocks_any = 0;
+    uint64_t blocks_any = 0;
 };
 
 // One chunk of channels of the host-buffer path in flight: pinned and device buffers for the packed
@@ -507,7 +513,15 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             p.lf_flags |= extra_flags;
             r.any = true;
             if (p.mode == psk::PLAN_FAST) {
-                if (p.n_out) {
+                if (p.n_out && (p.lf_flags & psk::PLAN_ANYFRONT)) {
+                    r.any_emit = true;
+                    r.cnt_any++;
+                    const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
+                    r.blocks_any += nb;
+                    if (nb > r.max_blocks_any) r.max_blocks_any = nb;
+                    if (p.lf_n > r.max_n_any) r.max_n_any = p.lf_n;
+                    if (p.A > r.max_A_any) r.max_A_any = p.A;
+                } else if (p.n_out) {
                     r.any_emit = true;
                     const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
                     r.need_SH[p.S][Hh] = true;
@@ -574,19 +588,22 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     uint32_t *const h_list = reinterpret_cast<uint32_t *>(h->h_plans[slot] + nch);
     const uint32_t *const d_list = reinterpret_cast<const uint32_t *>(h->d_plans[slot] + nch);
     uint32_t off_SH[33][17] = {}, off_quiet = 0;
+    const uint32_t off_any = res.cnt_quiet;
     {
-        uint32_t run = res.cnt_quiet;
+        uint32_t run = res.cnt_quiet + res.cnt_any;
         for (int S : kFastS)
             for (int H : kClassH) {
                 off_SH[S][H] = run;
                 run += res.cnt_SH[S][H];
             }
-        uint32_t fill_SH[33][17] = {}, fill_quiet = 0;
+        uint32_t fill_SH[33][17] = {}, fill_quiet = 0, fill_any = 0;
         for (uint32_t i = 0; i < nch; i++) {
             const psk::ChanPlan &p = plans[i];
             if (p.mode != psk::PLAN_FAST)
                 continue;
-            if (p.n_out) {
+            if (p.n_out && (p.lf_flags & psk::PLAN_ANYFRONT)) {
+                h_list[off_any + fill_any++] = i;
+            } else if (p.n_out) {
                 const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
                 h_list[off_SH[p.S][Hh] + fill_SH[p.S][Hh]++] = i;
             } else {
@@ -599,8 +616,31 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // that the class makes a few thousand tiles.
     bool tiled_SH[33][17] = {};
     bool pf_second = false;
+    uint32_t tiles_max_any = 0;
     uint32_t tiles_max_SH[33][17] = {};
     size_t tile_syms = 0, tile_count = 0;
+    if (res.cnt_any) {
+        // (window classes without a wave-scan instantiation: always tiled, whatever the option says -- the alternative is the
+        // reference-order kernel; a tile at least as long as the longest window, so that rebuilding it stays a fraction)
+        uint64_t K = res.blocks_any / kTiledTargetTiles;
+        K = K < 2 ? 2 : K > 16 ? 16 : K;
+        const uint64_t k_win = (res.max_A_any + 127u) / 128u;
+        if (K < k_win)
+            K = k_win > 64 ? 64 : k_win;
+        tiles_max_any = (uint32_t)((res.max_blocks_any + K - 1) / K);
+        for (uint32_t i = 0; i < res.cnt_any; i++) {
+            psk::ChanPlan &p = plans[h_list[off_any + i]];
+            const uint64_t nb = (p.n_out + 127u) / 128u;
+            p.lf_flags |= psk::PLAN_TILED;
+            if (h->opt_pfit && p.lf_len0 == p.lf_n && p.lf_n >= 2)
+                p.lf_flags |= psk::PLAN_PFIT;
+            p.tile_blocks = (uint32_t)K;
+            p.tile_base = (uint32_t)tile_count;
+            p.tile_off = tile_syms;
+            tile_count += (size_t)((nb + K - 1) / K);
+            tile_syms += (size_t)nb * 128u;
+        }
+    }
     if (h->opt_tiled) {
         for (int S : kFastS)
             for (int H : kClassH) {
@@ -659,7 +699,14 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
             }
             if (!got) {
                 (void)hipGetLastError();
-                for (uint32_t i = 0; i < nch; i++) plans[i].lf_flags &= ~(uint32_t)(psk::PLAN_TILED | psk::PLAN_PFIT);
+                for (uint32_t i = 0; i < nch; i++) {
+                    if (plans[i].lf_flags & psk::PLAN_ANYFRONT) {  // (no kernel but the reference-order one is left for these)
+                        plans[i].mode = psk::PLAN_SEQ;
+                        res.any_seq = true;
+                    }
+                    plans[i].lf_flags &= ~(uint32_t)(psk::PLAN_TILED | psk::PLAN_PFIT | psk::PLAN_ANYFRONT);
+                }
+                res.cnt_any = 0;
                 for (auto &row : tiled_SH)
                     for (bool &t : row) t = false;
                 tile_syms = 0;
@@ -712,6 +759,19 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         // one after the other each would leave part of the machine idle.  The classes go to side streams forked off
         // the caller's stream behind the plan upload and joined again in front of the reference-order kernel; the
         // deepest histories (fewest waves per CU, longest tails) are launched first.
+        if (res.cnt_any) {
+            const uint32_t y_len = ring_floats(res.max_n_any, 512u);
+            PSK_HIP(psk::launch_tile_front_any(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_ring,
+                                               h->lim.ring_cap, h->d_tiles, h->d_traw, h->d_ts, h->pf.chan, stream));
+            if (h->opt_pfit)
+                PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_ring,
+                                         h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, h->pf,
+                                         pf_second, stream));
+            PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, h->d_state, h->d_ring, h->lim.ring_cap,
+                                         h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, h->pf, stream));
+            PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_tiles,
+                                          h->d_ts, h->d_test, stream));
+        }
         struct Cls {
             int S, H;
         };

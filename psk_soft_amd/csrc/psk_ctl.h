@@ -83,6 +83,9 @@ inline bool fast_kernel_has(uint32_t S, uint32_t A)
         return false;
     return A <= (S <= 16 ? 1024u : 512u);
 }
+// window classes without an instantiation go through the time-tiled kernels behind a front stage that takes samplesPerBaud
+// and numAvg at run time (psk_tile.hip: psk_tile_front_any_kernel; up to 16 timing phases per lane)
+inline bool any_front_has(uint32_t S) { return S >= 2 && S <= 1024; }
 // history blocks of the instantiation that takes a window of numAvg symbols
 inline int fast_hist_blocks(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : A <= 512u ? 4 : 8; }
 
@@ -214,6 +217,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
     plan.count0 = (uint32_t)c.count;
 
     uint64_t n_out = 0;
+    bool any_front = false;  // (regular window mode) the window class has no wave-scan instantiation
     if (S == 1) {
         // :445 nothing is pushed; :454 index==lastSample needs index==0; :457 size==numDataPts
         if (c.index == 0) {
@@ -248,7 +252,8 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         c.index = c.ring_len % S;
         c.count = (c.count + n_out) % kResyncCount;  // :581-583
         plan.ring_len1 = (uint32_t)c.ring_len;
-        bool fast_ok = !lim.force_seq && fast_kernel_has((uint32_t)S, (uint32_t)A) && c.lf_n <= lim.fast_fit_max &&
+        any_front = !fast_kernel_has((uint32_t)S, (uint32_t)A);
+        bool fast_ok = !lim.force_seq && (!any_front || any_front_has((uint32_t)S)) && c.lf_n <= lim.fast_fit_max &&
                        n_out <= kResyncCount &&
                        ((plan_lf_count0(c)) + n_out <= kResyncCount);
         plan.mode = (n_out == 0 || fast_ok) ? PLAN_FAST : PLAN_SEQ;
@@ -264,6 +269,8 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
     plan.lf_xdelta = c.lf_xdelta;
     plan.lf_flags = 0;
     plan.n_out = n_out;
+    if (plan.mode == PLAN_FAST && n_out && any_front)
+        plan.lf_flags |= PLAN_ANYFRONT;
     if (plan.mode != PLAN_SKIP && c.lf_recompute_pending) {
         plan.lf_flags |= LF_RECOMPUTE;
         plan.lf_count0 = 0;

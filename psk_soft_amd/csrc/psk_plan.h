@@ -31,6 +31,10 @@ enum LfFlags : uint32_t {
     // ... and, of those, the call's feedback unwrap and fit are attempted in parallel along time (psk_pfit.h): the fit
     // window is full at the start of the call
     PLAN_PFIT = 8u,
+    // a window class the wave-scan kernels have no instantiation for (samplesPerBaud > 32, numAvg > 1024): always through
+    // the time-tiled kernels, behind the front stage that takes samplesPerBaud and numAvg at run time (psk_tile.hip:
+    // psk_tile_front_any_kernel); what that hands over is the reference-order kernel's
+    PLAN_ANYFRONT = 16u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582

@@ -54,6 +54,177 @@ PSK_DEV bool tile_fold(const ChanPlan &p, const TileInfo *ti, int n_tiles, int l
     return refuse;
 }
 
+// ---- front, any samplesPerBaud and numAvg: grid (tiles, channels of the launch) ----
+// The instantiated front kernel keeps a symbol's samplesPerBaud energies in one lane and scans along the symbols; this
+// one lays the timing PHASES across the lanes (phase k in lane k mod 64, up to 16 a lane) and walks the tile's symbols
+// one after the other, every lane updating its own window sums in the reference's order (cpp/psk_soft.cpp:445-452: a
+// symbol's energies are added as its samples arrive; :572-577: the leaving symbol's are subtracted after the pick):
+// coalesced loads whatever the samplesPerBaud, no window history to keep whatever the numAvg.  The pick is a reduction
+// over the wave per symbol (first maximum, :462); picked samples wait in lane (symbol mod 64) until 64 are there and take
+// the M-th power and atan2f together.  A tile's first window is a fresh sum of the numAvg - 1 symbols in front of it --
+// the call's first one IS resyncEnergy's sum (:619-636), the others equal the reference's running sums while those are
+// exact: the tile reports the exponent range of every energy it saw and the smallest gap between best and runner-up,
+// the fit kernel's fold decides as for the instantiated front kernel.  ~25 us per block of 128 symbols and tile
+// (the reference-order kernel: 600).
+constexpr int kAnyPhases = 16;  // phases per lane: samplesPerBaud <= 1024
+struct AnyTop {
+    double best, second;
+    int k;
+};
+PSK_DEV AnyTop any_merge(const AnyTop &a, const AnyTop &b)  // first maximum: the larger sum, the lower phase on a tie
+{
+    const bool b_wins = b.best > a.best || (b.best == a.best && b.k < a.k);
+    AnyTop r;
+    r.best = b_wins ? b.best : a.best;
+    r.k = b_wins ? b.k : a.k;
+    const double loser = b_wins ? a.best : b.best;
+    const double s2 = a.second > b.second ? a.second : b.second;
+    r.second = loser > s2 ? loser : s2;
+    return r;
+}
+__global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                                const ChanState *__restrict__ states, const float2 *__restrict__ rings,
+                                                                uint32_t ring_cap, TileInfo *__restrict__ tiles, float *__restrict__ t_raw,
+                                                                float2 *__restrict__ t_s, PfChan *__restrict__ pf_chan)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = list[blockIdx.y];
+    const ChanPlan &p = plans[bi];
+    if (!tile_plan_mine(p) || !(p.lf_flags & PLAN_ANYFRONT))
+        return;
+    const int n_out = (int)p.n_out;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    const int c_begin = (int)(blockIdx.x * p.tile_blocks);
+    if (c_begin >= n_blocks)
+        return;
+    if (blockIdx.x == 0 && lane == 0)
+        pf_chan[bi].fail = pf_chan[bi].done = pf_chan[bi].slow_blocks = pf_chan[bi].retry = 0u;
+    const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
+    const int i_begin = c_begin * kB, i_end = c_end * kB < n_out ? c_end * kB : n_out;
+    const uint32_t ch = ch0 + bi;
+    XView X;
+    X.ring = reinterpret_cast<const f2g *>(rings + ((size_t)ch * 2u + p.ring_src) * ring_cap);
+    X.in = reinterpret_cast<const f2g *>(p.in);
+    X.L0 = p.ring_len0;
+    const int S = (int)p.S, A = (int)p.A;
+    const uint32_t M = p.M;
+    const int nk = (S + kWave - 1) / kWave;
+    const AtanTabDev atab = atan_tab_dev(lane);
+    float *raw_row = t_raw + p.tile_off;
+    float2 *s_row = t_s + p.tile_off;
+
+    double W[kAnyPhases];
+#pragma unroll
+    for (int j = 0; j < kAnyPhases; j++) W[j] = 0.0;
+    unsigned umax = 0u, umin1 = 0xFFFFFFFFu;
+    bool refuse = false;
+    float emax = 0.0f;
+    // energy of sample `k` of symbol `tau` (0 past the symbol's end), with the guard's bookkeeping
+    auto energy = [&](long long tau, int k) -> float {
+        if (k >= S)
+            return 0.0f;
+        const float2 v = x_at(X, (uint64_t)tau * (uint64_t)S + (uint64_t)k);
+        const float e = norm_f(v.x, v.y);
+        const unsigned eb = __float_as_uint(e);
+        if (eb >= 0x7F800000u)
+            refuse = true;  // (inf / NaN: the reference-order kernel's)
+        umax = eb > umax ? eb : umax;
+        umin1 = (eb - 1u) < umin1 ? (eb - 1u) : umin1;
+        emax = __builtin_fmaxf(emax, e);
+        return e;
+    };
+    // the window in front of the tile's first symbol: symbols i_begin .. i_begin + numAvg - 2, in order
+    for (long long tau = i_begin; tau < (long long)i_begin + A - 1; tau++) {
+#pragma unroll
+        for (int j = 0; j < kAnyPhases; j++)
+            if (j < nk)
+                W[j] += (double)energy(tau, lane + kWave * j);
+    }
+    float gap_rel = __builtin_inff(), wmax = 0.0f;
+    float2 pk = make_float2(0.0f, 0.0f);
+    int kb = 0, k_last = 0;
+    for (int i = i_begin; i < i_end; i++) {
+        // the newest symbol of the window arrives
+#pragma unroll
+        for (int j = 0; j < kAnyPhases; j++)
+            if (j < nk)
+                W[j] += (double)energy((long long)i + A - 1, lane + kWave * j);
+        // first maximum over the phases, and the runner-up
+        AnyTop top;
+        top.best = -__builtin_inf();
+        top.second = -__builtin_inf();
+        top.k = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < kAnyPhases; j++) {
+            const int k = lane + kWave * j;
+            if (j < nk && k < S) {
+                AnyTop one;
+                one.best = W[j];
+                one.second = -__builtin_inf();
+                one.k = k;
+                top = any_merge(top, one);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+            AnyTop o;
+            const int src = (lane ^ m) << 2;
+            o.best = __hiloint2double(bperm_addr(src, __double2hiint(top.best)), bperm_addr(src, __double2loint(top.best)));
+            o.second = __hiloint2double(bperm_addr(src, __double2hiint(top.second)), bperm_addr(src, __double2loint(top.second)));
+            o.k = bperm_addr(src, top.k);
+            top = any_merge(top, o);
+        }
+        const int kbest = __builtin_amdgcn_readfirstlane(top.k);
+        k_last = kbest;
+        {
+            const float best_f = (float)top.best;
+            wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
+            const float g = (float)(top.best - top.second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
+            gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
+        }
+        // the sample at that phase (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+        const float2 v = x_at(X, (uint64_t)i * (uint64_t)S + (uint64_t)kbest);
+        const int slot = i & (kWave - 1);
+        pk = lane == slot ? v : pk;
+        kb = lane == slot ? kbest : kb;
+        // the oldest symbol of the window leaves
+#pragma unroll
+        for (int j = 0; j < kAnyPhases; j++)
+            if (j < nk)
+                W[j] -= (double)energy(i, lane + kWave * j);
+        if (slot == kWave - 1 || i == i_end - 1) {
+            cf32 sv;
+            sv.re = pk.x, sv.im = pk.y;
+            const cf32 pw = cpow_uint<false>(sv, M);
+            const float raw = atan2f_wave(pw.im, pw.re, atab);
+            const int mine = i - slot + lane;
+            if (lane <= slot) {
+                if (!(is_fin(pw.re) && is_fin(pw.im)))
+                    refuse = true;
+                raw_row[mine] = raw;
+                s_row[mine] = pk;
+                if (p.sidx)
+                    p.sidx[mine] = (int16_t)(unsigned short)kb;
+            }
+        }
+    }
+    const unsigned umax_w = wave_max_u32(umax), umin1_w = wave_min_u32(umin1);
+    const bool refuse_w = vote_any(refuse);
+    const float emax_w = wave_max_f32(__builtin_fmaxf(emax, 0.0f));
+    if (lane == 0) {
+        TileInfo &t = tiles[p.tile_base + blockIdx.x];
+        t.umax = umax_w;
+        t.umin1 = umin1_w;
+        t.refuse = refuse_w ? 1u : 0u;
+        t.gap_rel = gap_rel;
+        t.wmax = wmax;
+        t.stat_exact = (uint32_t)(c_end - c_begin);
+        t.last_k = (uint32_t)k_last;
+        t.cap = __builtin_inff();
+        t.emax = emax_w;
+    }
+}
+
 // ---- the parallel fit verified (psk_pfit.h): end of the call from its results ----
 PSK_DEV void pf_commit(const ChanPlan &p, uint32_t bi, uint32_t ch, ChanState *st, float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap,
                        float *yring, uint32_t ymask, TileInfo *ti, int n_tiles, int exact_blocks, const float2 *t_s, const float *t_est,
@@ -304,6 +475,17 @@ hipError_t launch_tile_front(int S, int H, PSK_TILE_FRONT_ARGS)
     PSK_TCASE(2) PSK_TCASE(3) PSK_TCASE(4) PSK_TCASE(5) PSK_TCASE(6) PSK_TCASE(7) PSK_TCASE(8) PSK_TCASE(9)
     PSK_TCASE(10) PSK_TCASE(11) PSK_TCASE(12) PSK_TCASE(13) PSK_TCASE(14) PSK_TCASE(15) PSK_TCASE(16)
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+                                 const ChanState *states, const float2 *rings, uint32_t ring_cap, TileInfo *tiles, float *t_raw, float2 *t_s,
+                                 PfChan *pf_chan, hipStream_t stream)
+{
+    if (!nch || !max_tiles)
+        return hipSuccess;
+    hipLaunchKernelGGL(psk_tile_front_any_kernel, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap, tiles,
+                       t_raw, t_s, pf_chan);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,

@@ -280,8 +280,8 @@ def test_host_sized_energy_ring(oracle_mod):
 def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     """One instantiation of the wave-scan kernel per samplesPerBaud 2 .. 32 and window class (numAvg
     <= 128 / <= 256 / <= 512, and <= 1024 up to samplesPerBaud 16): every one of them against the
-    oracle, ragged packets, shaped and rectangular pulses; samplesPerBaud 33 and 40 take the
-    reference-order kernel."""
+    oracle, ragged packets, shaped and rectangular pulses; samplesPerBaud 33 and 40 have none and go
+    through the time-tiled kernels' run-time front stage (round 1: the reference-order kernel)."""
     import random as _random
 
     from psk_soft_amd.stimulus import gen_psk, synth_channel
@@ -312,7 +312,7 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
             for key in got[c]:
                 got[c][key].append(res[c][key])
     st = h.stats()
-    assert st["channels_sequential"] - st["channels_guard"] == 6, st  # samplesPerBaud 33 and 40, three windows each
+    assert st["channels_sequential"] - st["channels_guard"] == 0 and st["channels_tiled"] >= 6, st  # (33 and 40, three windows each)
     for c in range(n_ch):
         o = oracle_mod.OracleComponent()
         for kk, v in props[c].items():

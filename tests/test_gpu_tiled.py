@@ -319,3 +319,35 @@ def test_parity_suite_through_the_tiles(oracle_mod, monkeypatch, name):
     monkeypatch.setenv("PSK_SOFT_TIME_TILED", "2")
     monkeypatch.setenv("PSK_SOFT_PARALLEL_FIT", "2")
     getattr(tp, name)(oracle_mod)
+
+
+ANY_CASES = [
+    # M, S, diff, numAvg, phaseAvg, N, packet
+    (4, 40, 0, 100, 50, 40 * 3000, None),
+    (4, 64, 1, 100, 50, 64 * 2500, 64 * 1000 + 17),
+    (8, 33, 0, 60, 200, 33 * 2600, 33 * 900),
+    (2, 8, 0, 2000, 50, 8 * 9000, 8 * 3000 + 5),
+    (4, 10, 0, 1025, 385, 10 * 6000, None),
+    (4, 24, 0, 600, 50, 24 * 4000, 24 * 1500),
+    (4, 100, 0, 30, 10, 100 * 1500, 100 * 500 + 3),
+    (4, 1024, 0, 3, 5, 1024 * 300, None),
+]
+
+
+@pytest.mark.parametrize("M,S,diff,A,n,N,packet", ANY_CASES)
+def test_window_classes_without_an_instantiation(oracle_mod, M, S, diff, A, n, N, packet):
+    """samplesPerBaud > 32, numAvg > 1024 (> 512 for samplesPerBaud > 16): no wave-scan instantiation; the time-tiled kernels
+    behind the front stage that takes both at run time (timing phases across the lanes, symbols one after the other) carry
+    them -- round 1: the reference-order kernel, 4.7 us per symbol."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq = synth_channel(53 * M + S, M, S, N)
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=diff)
+    ref = oracle_run(oracle_mod, iq, props, packet=packet)
+    h = _handle(1, max_window_samples=S * A + 64, max_phase_avg=512)
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01, packet)
+    st = h.stats()
+    assert st["channels_fast"] == 1 and st["channels_sequential"] == 0 and st["channels_tiled"] == 1, st
+    assert_parity(got, ref, "any front M%d S%d A%d n%d" % (M, S, A, n))
+    h.close()
