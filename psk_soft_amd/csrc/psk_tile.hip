@@ -109,6 +109,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     const int S = (int)p.S, A = (int)p.A;
     const uint32_t M = p.M;
     const int nk = (S + kWave - 1) / kWave;
+    int span = 1;  // lanes that hold phases, rounded up to a power of two
+    while (span < S && span < kWave) span <<= 1;
     const AtanTabDev atab = atan_tab_dev(lane);
     float *raw_row = t_raw + p.tile_off;
     float2 *s_row = t_s + p.tile_off;
@@ -167,6 +169,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
         }
 #pragma unroll
         for (int m = 1; m < kWave; m <<= 1) {
+            if (m >= span)  // (lanes beyond samplesPerBaud hold nothing: fewer steps for narrow symbols; wave-uniform)
+                break;
             AnyTop o;
             const int src = (lane ^ m) << 2;
             o.best = __hiloint2double(bperm_addr(src, __double2hiint(top.best)), bperm_addr(src, __double2loint(top.best)));
@@ -175,6 +179,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
             top = any_merge(top, o);
         }
         const int kbest = __builtin_amdgcn_readfirstlane(top.k);
+        top.best = read_lane(top.best, 0);
+        top.second = read_lane(top.second, 0);
         k_last = kbest;
         {
             const float best_f = (float)top.best;
