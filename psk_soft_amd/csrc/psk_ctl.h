@@ -223,7 +223,11 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         if (c.index == 0) {
             if (c.ring_len == D) {
                 n_out = N;
-                plan.mode = PLAN_SEQ_S1;
+                // (a symbol per sample, no timing recovery: the time-tiled kernels behind their run-time front stage, which has
+                // nothing to pick there; the reference-order kernel for what the fit limits exclude)
+                any_front = !lim.force_seq && n_out > 0 && c.lf_n <= lim.fast_fit_max && n_out <= kResyncCount &&
+                            plan_lf_count0(c) + n_out <= kResyncCount;
+                plan.mode = any_front ? PLAN_FAST : PLAN_SEQ_S1;
             }
         } else {
             c.index += N;  // lastSample==0 is never reached again

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
     const bool redo = (p.mode == PLAN_FAST) && (st->guard == 1u);  // both wave-scan kernels refused
     if (!(p.mode == PLAN_SEQ || p.mode == PLAN_SEQ_S1 || redo))
         return;
+    // samplesPerBaud == 1 (a symbol per sample, no timing recovery): planned for this kernel, or handed over by the time-tiled ones
+    const bool s1 = p.mode == PLAN_SEQ_S1 || (redo && p.S == 1u);
     float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
     const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
     float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         E.n_emit = 0;
         if (p.lf_flags & LF_RECOMPUTE)
             E.fit.reset_sums();
-        if (p.mode != PLAN_SEQ_S1) {  // resyncEnergy ran in this call's prologue, :619-636
+        if (!s1) {  // resyncEnergy ran in this call's prologue, :619-636
             for (uint32_t k = 0; k < S; k++) symE[k] = 0.0;
             for (uint64_t j = 0; j < X.L0; j++) {
                 const float2 v = x_at(X, j);
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
                 cf32 cur;
                 cur.re = v.x;
                 cur.im = v.y;
-                if (p.mode == PLAN_SEQ_S1) {  // samplesPerBaud == 1, :468-469
+                if (s1) {  // samplesPerBaud == 1, :468-469
                     seq_emit_symbol(E, cur, 0, false);
                     continue;
                 }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         sh_head = head;
     }
     __syncthreads();
-    if (p.mode != PLAN_SEQ_S1) {
+    if (!s1) {
         const uint64_t h = sh_head;
         for (uint32_t j = lane; j < p.ring_len1; j += kWave) ring_dst[j] = x_at(X, h + j);
     }

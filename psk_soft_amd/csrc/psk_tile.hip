@@ -109,6 +109,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     const int S = (int)p.S, A = (int)p.A;
     const uint32_t M = p.M;
     const int nk = (S + kWave - 1) / kWave;
+    const bool timing = S > 1;  // (samplesPerBaud == 1: a symbol per sample, nothing to pick, cpp/psk_soft.cpp:468-469)
     int span = 1;  // lanes that hold phases, rounded up to a power of two
     while (span < S && span < kWave) span <<= 1;
     const AtanTabDev atab = atan_tab_dev(lane);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
         return e;
     };
     // the window in front of the tile's first symbol: symbols i_begin .. i_begin + numAvg - 2, in order
-    for (long long tau = i_begin; tau < (long long)i_begin + A - 1; tau++) {
+    for (long long tau = i_begin; timing && tau < (long long)i_begin + A - 1; tau++) {
 #pragma unroll
         for (int j = 0; j < kAnyPhases; j++)
             if (j < nk)
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     float2 pk = make_float2(0.0f, 0.0f);
     int kb = 0, k_last = 0;
     for (int i = i_begin; i < i_end; i++) {
+        int kbest = 0;
+        if (timing) {
         // the newest symbol of the window arrives
 #pragma unroll
         for (int j = 0; j < kAnyPhases; j++)
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
             o.k = bperm_addr(src, top.k);
             top = any_merge(top, o);
         }
-        const int kbest = __builtin_amdgcn_readfirstlane(top.k);
+        kbest = __builtin_amdgcn_readfirstlane(top.k);
         top.best = read_lane(top.best, 0);
         top.second = read_lane(top.second, 0);
         k_last = kbest;
@@ -188,16 +191,22 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
             const float g = (float)(top.best - top.second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
             gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
         }
+        }  // (timing)
         // the sample at that phase (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
-        const float2 v = x_at(X, (uint64_t)i * (uint64_t)S + (uint64_t)kbest);
+        // (samplesPerBaud == 1 takes the packet's sample as it comes, :468-469: the deque may still hold stale samples of an
+        // earlier configuration, which that mode never touches)
+        const uint64_t j_pick = timing ? (uint64_t)i * (uint64_t)S + (uint64_t)kbest : (uint64_t)X.L0 + (uint64_t)i;
+        const float2 v = x_at(X, j_pick);
         const int slot = i & (kWave - 1);
         pk = lane == slot ? v : pk;
         kb = lane == slot ? kbest : kb;
         // the oldest symbol of the window leaves
+        if (timing) {
 #pragma unroll
-        for (int j = 0; j < kAnyPhases; j++)
-            if (j < nk)
-                W[j] -= (double)energy(i, lane + kWave * j);
+            for (int j = 0; j < kAnyPhases; j++)
+                if (j < nk)
+                    W[j] -= (double)energy(i, lane + kWave * j);
+        }
         if (slot == kWave - 1 || i == i_end - 1) {
             cf32 sv;
             sv.re = pk.x, sv.im = pk.y;
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                     refuse = true;
                 raw_row[mine] = raw;
                 s_row[mine] = pk;
-                if (p.sidx)
+                if (p.sidx && timing)
                     p.sidx[mine] = (int16_t)(unsigned short)kb;
             }
         }

@@ -331,6 +331,11 @@ ANY_CASES = [
     (4, 24, 0, 600, 50, 24 * 4000, 24 * 1500),
     (4, 100, 0, 30, 10, 100 * 1500, 100 * 500 + 3),
     (4, 1024, 0, 3, 5, 1024 * 300, None),
+    (4, 1, 0, 0, 50, 20000, 7001),    # samplesPerBaud 1 with numAvg 0: a symbol per sample, no timing recovery (quirk Q11)
+    (8, 1, 1, 0, 200, 30000, None),
+    (2, 1, 0, 0, 3, 5000, 64),
+    (8, 1, 0, 0, 60, 600, None),
+    (8, 1, 0, 0, 60, 20000, 3000),
 ]
 
 
@@ -351,3 +356,22 @@ def test_window_classes_without_an_instantiation(oracle_mod, M, S, diff, A, n, N
     assert st["channels_fast"] == 1 and st["channels_sequential"] == 0 and st["channels_tiled"] == 1, st
     assert_parity(got, ref, "any front M%d S%d A%d n%d" % (M, S, A, n))
     h.close()
+
+
+def test_run_time_front_hands_over(oracle_mod):
+    """What the run-time front stage does not carry (a non-finite sample) comes out of the reference-order kernel with the
+    reference's values -- samplesPerBaud 40 through its regular loop, samplesPerBaud 1 through its symbol-per-sample one."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    for S, A in ((40, 100), (1, 0)):
+        iq = synth_channel(71 + S, 4, max(S, 1), max(S, 1) * 3000).copy()
+        iq[2 * (max(S, 1) * 2000 + 3)] = np.inf
+        props = dict(samplesPerBaud=S, constelationSize=4, numAvg=A, phaseAvg=50)
+        ref = oracle_run(oracle_mod, iq, props, packet=max(S, 1) * 1000)
+        h = _handle(1, max_window_samples=max(S * A, 16) + 64)
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, max(S, 1) * 1000)
+        st = h.stats()
+        assert st["channels_sequential"] == 1 and st["channels_guard"] == 1, st
+        assert_parity(got, ref, "S%d" % S)
+        h.close()
