@@ -82,6 +82,34 @@ PSK_DEV AnyTop any_merge(const AnyTop &a, const AnyTop &b)  // first maximum: th
     r.second = loser > s2 ? loser : s2;
     return r;
 }
+// the wave's (best, runner-up, phase) in lane 63: the scan pattern of wave_scan_f64 (row_shr 1, 2, 4, 8, row_bcast 15 and 31)
+// with any_merge in place of the addition; lanes without a source take the identity
+template <int CTRL, int ROW_MASK>
+PSK_DEV AnyTop any_from(const AnyTop &t)
+{
+    const int ninf_hi = (int)0xFFF00000u;
+    AnyTop o;
+    o.best = __hiloint2double(__builtin_amdgcn_update_dpp(ninf_hi, __double2hiint(t.best), CTRL, ROW_MASK, 0xF, false),
+                              __builtin_amdgcn_update_dpp(0, __double2loint(t.best), CTRL, ROW_MASK, 0xF, false));
+    o.second = __hiloint2double(__builtin_amdgcn_update_dpp(ninf_hi, __double2hiint(t.second), CTRL, ROW_MASK, 0xF, false),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(t.second), CTRL, ROW_MASK, 0xF, false));
+    o.k = __builtin_amdgcn_update_dpp(0x7fffffff, t.k, CTRL, ROW_MASK, 0xF, false);
+    return o;
+}
+PSK_DEV AnyTop any_reduce(AnyTop t)
+{
+    t = any_merge(t, any_from<0x111, 0xF>(t));
+    t = any_merge(t, any_from<0x112, 0xF>(t));
+    t = any_merge(t, any_from<0x114, 0xF>(t));
+    t = any_merge(t, any_from<0x118, 0xF>(t));
+    t = any_merge(t, any_from<0x142, 0xA>(t));
+    t = any_merge(t, any_from<0x143, 0xC>(t));
+    AnyTop r;
+    r.best = read_lane(t.best, 63);
+    r.second = read_lane(t.second, 63);
+    r.k = __builtin_amdgcn_readlane(t.k, 63);
+    return r;
+}
 __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                                 const ChanState *__restrict__ states, const float2 *__restrict__ rings,
                                                                 uint32_t ring_cap, TileInfo *__restrict__ tiles, float *__restrict__ t_raw,
@@ -110,8 +138,6 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     const uint32_t M = p.M;
     const int nk = (S + kWave - 1) / kWave;
     const bool timing = S > 1;  // (samplesPerBaud == 1: a symbol per sample, nothing to pick, cpp/psk_soft.cpp:468-469)
-    int span = 1;  // lanes that hold phases, rounded up to a power of two
-    while (span < S && span < kWave) span <<= 1;
     const AtanTabDev atab = atan_tab_dev(lane);
     float *raw_row = t_raw + p.tile_off;
     float2 *s_row = t_s + p.tile_off;
@@ -144,76 +170,60 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                 W[j] += (double)energy(tau, lane + kWave * j);
     }
     float gap_rel = __builtin_inff(), wmax = 0.0f;
-    float2 pk = make_float2(0.0f, 0.0f);
     int kb = 0, k_last = 0;
+    // (the picked samples are only fetched when 64 picks are known: one load per lane in place of one per symbol)
     for (int i = i_begin; i < i_end; i++) {
         int kbest = 0;
         if (timing) {
-        // the newest symbol of the window arrives
+            // the newest symbol of the window arrives
 #pragma unroll
-        for (int j = 0; j < kAnyPhases; j++)
-            if (j < nk)
-                W[j] += (double)energy((long long)i + A - 1, lane + kWave * j);
-        // first maximum over the phases, and the runner-up
-        AnyTop top;
-        top.best = -__builtin_inf();
-        top.second = -__builtin_inf();
-        top.k = 0x7fffffff;
+            for (int j = 0; j < kAnyPhases; j++)
+                if (j < nk)
+                    W[j] += (double)energy((long long)i + A - 1, lane + kWave * j);
+            // first maximum over the phases, and the runner-up
+            AnyTop top;
+            top.best = -__builtin_inf();
+            top.second = -__builtin_inf();
+            top.k = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < kAnyPhases; j++) {
-            const int k = lane + kWave * j;
-            if (j < nk && k < S) {
-                AnyTop one;
-                one.best = W[j];
-                one.second = -__builtin_inf();
-                one.k = k;
-                top = any_merge(top, one);
+            for (int j = 0; j < kAnyPhases; j++) {
+                const int k = lane + kWave * j;
+                if (j < nk && k < S) {
+                    AnyTop one;
+                    one.best = W[j];
+                    one.second = -__builtin_inf();
+                    one.k = k;
+                    top = any_merge(top, one);
+                }
             }
-        }
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-            if (m >= span)  // (lanes beyond samplesPerBaud hold nothing: fewer steps for narrow symbols; wave-uniform)
-                break;
-            AnyTop o;
-            const int src = (lane ^ m) << 2;
-            o.best = __hiloint2double(bperm_addr(src, __double2hiint(top.best)), bperm_addr(src, __double2loint(top.best)));
-            o.second = __hiloint2double(bperm_addr(src, __double2hiint(top.second)), bperm_addr(src, __double2loint(top.second)));
-            o.k = bperm_addr(src, top.k);
-            top = any_merge(top, o);
-        }
-        kbest = __builtin_amdgcn_readfirstlane(top.k);
-        top.best = read_lane(top.best, 0);
-        top.second = read_lane(top.second, 0);
-        k_last = kbest;
-        {
+            top = any_reduce(top);
+            kbest = top.k;
+            k_last = kbest;
             const float best_f = (float)top.best;
             wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
             const float g = (float)(top.best - top.second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
             gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
-        }
-        }  // (timing)
-        // the sample at that phase (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
-        // (samplesPerBaud == 1 takes the packet's sample as it comes, :468-469: the deque may still hold stale samples of an
-        // earlier configuration, which that mode never touches)
-        const uint64_t j_pick = timing ? (uint64_t)i * (uint64_t)S + (uint64_t)kbest : (uint64_t)X.L0 + (uint64_t)i;
-        const float2 v = x_at(X, j_pick);
-        const int slot = i & (kWave - 1);
-        pk = lane == slot ? v : pk;
-        kb = lane == slot ? kbest : kb;
-        // the oldest symbol of the window leaves
-        if (timing) {
+            // the oldest symbol of the window leaves
 #pragma unroll
             for (int j = 0; j < kAnyPhases; j++)
                 if (j < nk)
                     W[j] -= (double)energy(i, lane + kWave * j);
         }
+        // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+        const int slot = i & (kWave - 1);
+        kb = lane == slot ? kbest : kb;
         if (slot == kWave - 1 || i == i_end - 1) {
+            const int mine = i - slot + lane;
+            const bool have = lane <= slot;
+            // (samplesPerBaud == 1 takes the packet's sample as it comes, :468-469: the deque may still hold stale samples of
+            // an earlier configuration, which that mode never touches)
+            const uint64_t j_pick = !have ? (uint64_t)X.L0 : timing ? (uint64_t)mine * (uint64_t)S + (uint64_t)kb : (uint64_t)X.L0 + (uint64_t)mine;
+            const float2 pk = x_at(X, j_pick);
             cf32 sv;
             sv.re = pk.x, sv.im = pk.y;
             const cf32 pw = cpow_uint<false>(sv, M);
             const float raw = atan2f_wave(pw.im, pw.re, atab);
-            const int mine = i - slot + lane;
-            if (lane <= slot) {
+            if (have) {
                 if (!(is_fin(pw.re) && is_fin(pw.im)))
                     refuse = true;
                 raw_row[mine] = raw;
