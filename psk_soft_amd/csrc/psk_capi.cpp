@@ -36,7 +36,7 @@ bool tile_front_has(int S, int H);
 hipError_t launch_tile_front(int S, int H, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                              const ChanState *states, const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw,
                              float2 *t_s, PfChan *pf_chan, hipStream_t stream);
-hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, uint32_t max_S,
                                  const ChanState *states, const float2 *rings, uint32_t ring_cap, TileInfo *tiles, float *t_raw, float2 *t_s,
                                  PfChan *pf_chan, hipStream_t stream);
 hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
@@ -169,7 +169,7 @@ struct PlanSummary {
     uint64_t blocks_SH[33][17] = {};
     uint32_t max_blocks_SH[33][17] = {};
     // the window classes without an instantiation (PLAN_ANYFRONT), one launch set for all of them
-    uint32_t cnt_any = 0, max_n_any = 0, max_A_any = 0, max_blocks_any = 0;
+    uint32_t cnt_any = 0, max_n_any = 0, max_A_any = 0, max_blocks_any = 0, max_S_any = 0;
     uint64_t blocks_any = 0;
 };
 
@@ -521,6 +521,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                     if (nb > r.max_blocks_any) r.max_blocks_any = nb;
                     if (p.lf_n > r.max_n_any) r.max_n_any = p.lf_n;
                     if (p.A > r.max_A_any) r.max_A_any = p.A;
+                    if (p.S > r.max_S_any) r.max_S_any = p.S;
                 } else if (p.n_out) {
                     r.any_emit = true;
                     const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
@@ -761,7 +762,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         // deepest histories (fewest waves per CU, longest tails) are launched first.
         if (res.cnt_any) {
             const uint32_t y_len = ring_floats(res.max_n_any, 512u);
-            PSK_HIP(psk::launch_tile_front_any(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_ring,
+            PSK_HIP(psk::launch_tile_front_any(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, res.max_S_any, h->d_state, h->d_ring,
                                                h->lim.ring_cap, h->d_tiles, h->d_traw, h->d_ts, h->pf.chan, stream));
             if (h->opt_pfit)
                 PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_ring,

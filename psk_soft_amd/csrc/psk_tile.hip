@@ -110,6 +110,10 @@ PSK_DEV AnyTop any_reduce(AnyTop t)
     r.k = __builtin_amdgcn_readlane(t.k, 63);
     return r;
 }
+// NP: phases a lane holds at most (samplesPerBaud <= 64 * NP for every channel of the launch).  With one phase a lane (NP = 1,
+// samplesPerBaud <= 64) the energies entering and leaving the window are asked for four symbols at a time: the walk is one
+// dependent step per symbol, and a step that waits for its own two loads is all latency.
+template <int NP>
 __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                                 const ChanState *__restrict__ states, const float2 *__restrict__ rings,
                                                                 uint32_t ring_cap, TileInfo *__restrict__ tiles, float *__restrict__ t_raw,
@@ -142,9 +146,9 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     float *raw_row = t_raw + p.tile_off;
     float2 *s_row = t_s + p.tile_off;
 
-    double W[kAnyPhases];
+    double W[NP];
 #pragma unroll
-    for (int j = 0; j < kAnyPhases; j++) W[j] = 0.0;
+    for (int j = 0; j < NP; j++) W[j] = 0.0;
     unsigned umax = 0u, umin1 = 0xFFFFFFFFu;
     bool refuse = false;
     float emax = 0.0f;
@@ -165,28 +169,46 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     // the window in front of the tile's first symbol: symbols i_begin .. i_begin + numAvg - 2, in order
     for (long long tau = i_begin; timing && tau < (long long)i_begin + A - 1; tau++) {
 #pragma unroll
-        for (int j = 0; j < kAnyPhases; j++)
+        for (int j = 0; j < NP; j++)
             if (j < nk)
                 W[j] += (double)energy(tau, lane + kWave * j);
     }
     float gap_rel = __builtin_inff(), wmax = 0.0f;
     int kb = 0, k_last = 0;
     // (the picked samples are only fetched when 64 picks are known: one load per lane in place of one per symbol)
-    for (int i = i_begin; i < i_end; i++) {
+    constexpr int U = NP == 1 ? 4 : 1;  // symbols whose energies are loaded together
+    for (int i0 = i_begin; i0 < i_end; i0 += U) {
+        float e_in[U][NP], e_out[U][NP];
+        if constexpr (U > 1) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool on = timing && i0 + u < i_end;
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    e_in[u][j] = (on && j < nk) ? energy((long long)(i0 + u) + A - 1, lane + kWave * j) : 0.0f;
+                    e_out[u][j] = (on && j < nk) ? energy(i0 + u, lane + kWave * j) : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+        const int i = i0 + u;
+        if (i >= i_end)
+            break;
         int kbest = 0;
         if (timing) {
             // the newest symbol of the window arrives
 #pragma unroll
-            for (int j = 0; j < kAnyPhases; j++)
+            for (int j = 0; j < NP; j++)
                 if (j < nk)
-                    W[j] += (double)energy((long long)i + A - 1, lane + kWave * j);
+                    W[j] += (double)(U > 1 ? e_in[u][j] : energy((long long)i + A - 1, lane + kWave * j));
             // first maximum over the phases, and the runner-up
             AnyTop top;
             top.best = -__builtin_inf();
             top.second = -__builtin_inf();
             top.k = 0x7fffffff;
 #pragma unroll
-            for (int j = 0; j < kAnyPhases; j++) {
+            for (int j = 0; j < NP; j++) {
                 const int k = lane + kWave * j;
                 if (j < nk && k < S) {
                     AnyTop one;
@@ -205,9 +227,9 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
             gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
             // the oldest symbol of the window leaves
 #pragma unroll
-            for (int j = 0; j < kAnyPhases; j++)
+            for (int j = 0; j < NP; j++)
                 if (j < nk)
-                    W[j] -= (double)energy(i, lane + kWave * j);
+                    W[j] -= (double)(U > 1 ? e_out[u][j] : energy(i, lane + kWave * j));
         }
         // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
         const int slot = i & (kWave - 1);
@@ -232,6 +254,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                     p.sidx[mine] = (int16_t)(unsigned short)kb;
             }
         }
+    }
     }
     const unsigned umax_w = wave_max_u32(umax), umin1_w = wave_min_u32(umin1);
     const bool refuse_w = vote_any(refuse);
@@ -502,14 +525,21 @@ hipError_t launch_tile_front(int S, int H, PSK_TILE_FRONT_ARGS)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
+hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, uint32_t max_S,
                                  const ChanState *states, const float2 *rings, uint32_t ring_cap, TileInfo *tiles, float *t_raw, float2 *t_s,
                                  PfChan *pf_chan, hipStream_t stream)
 {
     if (!nch || !max_tiles)
         return hipSuccess;
-    hipLaunchKernelGGL(psk_tile_front_any_kernel, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap, tiles,
-                       t_raw, t_s, pf_chan);
+    if (max_S <= 64u)
+        hipLaunchKernelGGL(psk_tile_front_any_kernel<1>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap,
+                           tiles, t_raw, t_s, pf_chan);
+    else if (max_S <= 256u)
+        hipLaunchKernelGGL(psk_tile_front_any_kernel<4>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap,
+                           tiles, t_raw, t_s, pf_chan);
+    else
+        hipLaunchKernelGGL(psk_tile_front_any_kernel<kAnyPhases>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings,
+                           ring_cap, tiles, t_raw, t_s, pf_chan);
     return hipGetLastError();
 }
 

@@ -19,7 +19,9 @@ from psk_soft_amd import lib as pl  # noqa: E402
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
-# PSK_FUZZ_S / PSK_FUZZ_A / PSK_FUZZ_N: comma-separated lists that replace the default draws (to aim a run at some instantiations)
+# PSK_FUZZ_S / PSK_FUZZ_A / PSK_FUZZ_N: comma-separated lists that replace the default draws (to aim a run at some instantiations);
+# PSK_FUZZ_WINDOW / PSK_FUZZ_PACKET: the handle's max_window_samples (samplesPerBaud * numAvg; the scripts set numAvg up to 300)
+# and max_packet_complex (a stream is up to 12000 symbols long), for samplesPerBaud beyond 64
 S_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_S"].split(",")] if os.environ.get("PSK_FUZZ_S") else (
     [2, 4, 5, 8, 8, 8, 10, 10, 16, 3, 7, 1, 6, 9, 11, 12, 13, 14, 15, 33] + list(range(17, 33)))
 A_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_A"].split(",")] if os.environ.get("PSK_FUZZ_A") else (
@@ -113,7 +115,8 @@ def main():
             if os.environ.get("PSK_FUZZ_DUMP") and int(os.environ["PSK_FUZZ_DUMP"]) == c:  # with a single-round replay: keep this channel's case
                 np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_case_sig.npy"), sig)
                 print("DUMPED channel %d: props=%s script=%s" % (c, p, ev))
-        h = pl.Handle(C, device=0, max_window_samples=33 * 1024 + 64, max_phase_avg=max(2048, max(N_CHOICES)))
+        h = pl.Handle(C, device=0, max_window_samples=int(os.environ.get("PSK_FUZZ_WINDOW", 33 * 1024 + 64)), max_phase_avg=max(2048, max(N_CHOICES)),
+                      max_packet_complex=int(os.environ.get("PSK_FUZZ_PACKET", 1 << 20)))
         h.configure(0, props)
         oracles = []
         for c in range(C):
