@@ -82,33 +82,39 @@ PSK_DEV AnyTop any_merge(const AnyTop &a, const AnyTop &b)  // first maximum: th
     r.second = loser > s2 ? loser : s2;
     return r;
 }
-// the wave's (best, runner-up, phase) in lane 63: the scan pattern of wave_scan_f64 (row_shr 1, 2, 4, 8, row_bcast 15 and 31)
-// with any_merge in place of the addition; lanes without a source take the identity
+// wave-wide maximum of a double / minimum of an unsigned: the scan pattern of wave_scan_f64 (row_shr 1, 2, 4, 8, row_bcast 15
+// and 31) with the extremum in place of the addition, lanes without a source taking the identity; the result sits in lane 63
 template <int CTRL, int ROW_MASK>
-PSK_DEV AnyTop any_from(const AnyTop &t)
+PSK_DEV double any_f64_from(double v)
 {
-    const int ninf_hi = (int)0xFFF00000u;
-    AnyTop o;
-    o.best = __hiloint2double(__builtin_amdgcn_update_dpp(ninf_hi, __double2hiint(t.best), CTRL, ROW_MASK, 0xF, false),
-                              __builtin_amdgcn_update_dpp(0, __double2loint(t.best), CTRL, ROW_MASK, 0xF, false));
-    o.second = __hiloint2double(__builtin_amdgcn_update_dpp(ninf_hi, __double2hiint(t.second), CTRL, ROW_MASK, 0xF, false),
-                                __builtin_amdgcn_update_dpp(0, __double2loint(t.second), CTRL, ROW_MASK, 0xF, false));
-    o.k = __builtin_amdgcn_update_dpp(0x7fffffff, t.k, CTRL, ROW_MASK, 0xF, false);
-    return o;
+    return __hiloint2double(__builtin_amdgcn_update_dpp((int)0xFFF00000u, __double2hiint(v), CTRL, ROW_MASK, 0xF, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false));
 }
-PSK_DEV AnyTop any_reduce(AnyTop t)
+PSK_DEV double any_max_f64(double v)
 {
-    t = any_merge(t, any_from<0x111, 0xF>(t));
-    t = any_merge(t, any_from<0x112, 0xF>(t));
-    t = any_merge(t, any_from<0x114, 0xF>(t));
-    t = any_merge(t, any_from<0x118, 0xF>(t));
-    t = any_merge(t, any_from<0x142, 0xA>(t));
-    t = any_merge(t, any_from<0x143, 0xC>(t));
-    AnyTop r;
-    r.best = read_lane(t.best, 63);
-    r.second = read_lane(t.second, 63);
-    r.k = __builtin_amdgcn_readlane(t.k, 63);
-    return r;
+    v = __builtin_fmax(v, any_f64_from<0x111, 0xF>(v));
+    v = __builtin_fmax(v, any_f64_from<0x112, 0xF>(v));
+    v = __builtin_fmax(v, any_f64_from<0x114, 0xF>(v));
+    v = __builtin_fmax(v, any_f64_from<0x118, 0xF>(v));
+    v = __builtin_fmax(v, any_f64_from<0x142, 0xA>(v));
+    v = __builtin_fmax(v, any_f64_from<0x143, 0xC>(v));
+    return read_lane(v, 63);
+}
+template <int CTRL, int ROW_MASK>
+PSK_DEV unsigned any_u32_from(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+PSK_DEV unsigned any_min_u32(unsigned v)
+{
+    unsigned o;
+    o = any_u32_from<0x111, 0xF>(v), v = o < v ? o : v;
+    o = any_u32_from<0x112, 0xF>(v), v = o < v ? o : v;
+    o = any_u32_from<0x114, 0xF>(v), v = o < v ? o : v;
+    o = any_u32_from<0x118, 0xF>(v), v = o < v ? o : v;
+    o = any_u32_from<0x142, 0xA>(v), v = o < v ? o : v;
+    o = any_u32_from<0x143, 0xC>(v), v = o < v ? o : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 // NP: phases a lane holds at most (samplesPerBaud <= 64 * NP for every channel of the launch).  With one phase a lane (NP = 1,
 // samplesPerBaud <= 64) the energies entering and leaving the window are asked for four symbols at a time: the walk is one
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
             for (int j = 0; j < NP; j++)
                 if (j < nk)
                     W[j] += (double)(U > 1 ? e_in[u][j] : energy((long long)i + A - 1, lane + kWave * j));
-            // first maximum over the phases, and the runner-up
+            // first maximum over the phases, and the runner-up (std::max_element, cpp/psk_soft.cpp:462, keeps the first of equal sums)
             AnyTop top;
             top.best = -__builtin_inf();
             top.second = -__builtin_inf();
@@ -218,12 +224,16 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                     top = any_merge(top, one);
                 }
             }
-            top = any_reduce(top);
-            kbest = top.k;
+            // (`top`: this lane's own phases.  The wave's largest sum; the lowest phase that holds it; the largest of all the others --
+            // the winner's lane puts up the runner-up among its own.  The sums are finite, or the tile refuses.)
+            const double best = any_max_f64(top.best);
+            const unsigned k_win = any_min_u32(top.best == best ? (unsigned)top.k : 0xFFFFFFFFu);
+            const double second = any_max_f64((unsigned)top.k == k_win ? top.second : top.best);
+            kbest = (int)k_win;
             k_last = kbest;
-            const float best_f = (float)top.best;
+            const float best_f = (float)best;
             wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
-            const float g = (float)(top.best - top.second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
+            const float g = (float)(best - second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
             gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
             // the oldest symbol of the window leaves
 #pragma unroll
