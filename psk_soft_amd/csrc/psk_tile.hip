@@ -117,7 +117,7 @@ PSK_DEV unsigned any_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 // NP: phases a lane holds at most (samplesPerBaud <= 64 * NP for every channel of the launch).  With one phase a lane (NP = 1,
-// samplesPerBaud <= 64) the energies entering and leaving the window are asked for four symbols at a time: the walk is one
+// samplesPerBaud <= 64) the energies entering and leaving the window are asked for eight symbols at a time: the walk is one
 // dependent step per symbol, and a step that waits for its own two loads is all latency.
 template <int NP>
 __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     float gap_rel = __builtin_inff(), wmax = 0.0f;
     int kb = 0, k_last = 0;
     // (the picked samples are only fetched when 64 picks are known: one load per lane in place of one per symbol)
-    constexpr int U = NP == 1 ? 4 : 1;  // symbols whose energies are loaded together
+    constexpr int U = NP == 1 ? 8 : 1;  // symbols whose energies are loaded together
     for (int i0 = i_begin; i0 < i_end; i0 += U) {
         float e_in[U][NP], e_out[U][NP];
         if constexpr (U > 1) {
@@ -198,52 +198,55 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-        const int i = i0 + u;
-        if (i >= i_end)
-            break;
-        int kbest = 0;
-        if (timing) {
-            // the newest symbol of the window arrives
+            const int i = i0 + u;
+            if (i >= i_end)
+                break;
+            int kbest = 0;
+            if (timing) {
+                // the newest symbol of the window arrives
 #pragma unroll
-            for (int j = 0; j < NP; j++)
-                if (j < nk)
-                    W[j] += (double)(U > 1 ? e_in[u][j] : energy((long long)i + A - 1, lane + kWave * j));
-            // first maximum over the phases, and the runner-up (std::max_element, cpp/psk_soft.cpp:462, keeps the first of equal sums)
-            AnyTop top;
-            top.best = -__builtin_inf();
-            top.second = -__builtin_inf();
-            top.k = 0x7fffffff;
+                for (int j = 0; j < NP; j++)
+                    if (j < nk)
+                        W[j] += (double)(U > 1 ? e_in[u][j] : energy((long long)i + A - 1, lane + kWave * j));
+                // first maximum over the phases, and the runner-up (std::max_element, cpp/psk_soft.cpp:462, keeps the first of equal sums)
+                AnyTop top;
+                top.best = -__builtin_inf();
+                top.second = -__builtin_inf();
+                top.k = 0x7fffffff;
 #pragma unroll
-            for (int j = 0; j < NP; j++) {
-                const int k = lane + kWave * j;
-                if (j < nk && k < S) {
-                    AnyTop one;
-                    one.best = W[j];
-                    one.second = -__builtin_inf();
-                    one.k = k;
-                    top = any_merge(top, one);
+                for (int j = 0; j < NP; j++) {
+                    const int k = lane + kWave * j;
+                    if (j < nk && k < S) {
+                        AnyTop one;
+                        one.best = W[j];
+                        one.second = -__builtin_inf();
+                        one.k = k;
+                        top = any_merge(top, one);
+                    }
                 }
-            }
-            // (`top`: this lane's own phases.  The wave's largest sum; the lowest phase that holds it; the largest of all the others --
-            // the winner's lane puts up the runner-up among its own.  The sums are finite, or the tile refuses.)
-            const double best = any_max_f64(top.best);
-            const unsigned k_win = any_min_u32(top.best == best ? (unsigned)top.k : 0xFFFFFFFFu);
-            const double second = any_max_f64((unsigned)top.k == k_win ? top.second : top.best);
-            kbest = (int)k_win;
-            k_last = kbest;
-            const float best_f = (float)best;
-            wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
-            const float g = (float)(best - second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
-            gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
-            // the oldest symbol of the window leaves
+                // (`top`: this lane's own phases.  The wave's largest sum; the lowest phase that holds it; the largest of all the others --
+                // the winner's lane puts up the runner-up among its own.  The sums are finite, or the tile refuses.)
+                const double best = any_max_f64(top.best);
+                const unsigned k_win = any_min_u32(top.best == best ? (unsigned)top.k : 0xFFFFFFFFu);
+                const double second = any_max_f64((unsigned)top.k == k_win ? top.second : top.best);
+                kbest = (int)k_win;
+                k_last = kbest;
+                const float best_f = (float)best;
+                wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
+                const float g = (float)(best - second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
+                gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
+                // the oldest symbol of the window leaves
 #pragma unroll
-            for (int j = 0; j < NP; j++)
-                if (j < nk)
-                    W[j] -= (double)(U > 1 ? e_out[u][j] : energy(i, lane + kWave * j));
+                for (int j = 0; j < NP; j++)
+                    if (j < nk)
+                        W[j] -= (double)(U > 1 ? e_out[u][j] : energy(i, lane + kWave * j));
+            }
+            // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+            kb = lane == (i & (kWave - 1)) ? kbest : kb;
         }
-        // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+        // (tiles start on block boundaries and U divides 64: a group of 64 picks ends with a chunk)
+        const int i = (i0 + U < i_end ? i0 + U : i_end) - 1;
         const int slot = i & (kWave - 1);
-        kb = lane == slot ? kbest : kb;
         if (slot == kWave - 1 || i == i_end - 1) {
             const int mine = i - slot + lane;
             const bool have = lane <= slot;
@@ -264,7 +267,6 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                     p.sidx[mine] = (int16_t)(unsigned short)kb;
             }
         }
-    }
     }
     const unsigned umax_w = wave_max_u32(umax), umin1_w = wave_min_u32(umin1);
     const bool refuse_w = vote_any(refuse);
