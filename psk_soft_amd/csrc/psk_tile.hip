@@ -100,6 +100,28 @@ PSK_DEV double any_max_f64(double v)
     v = __builtin_fmax(v, any_f64_from<0x143, 0xC>(v));
     return read_lane(v, 63);
 }
+// the same for U independent values, level by level: U chains that do not wait for one another
+template <int CTRL, int ROW_MASK, int U>
+PSK_DEV void any_max_f64_level(double (&v)[U])
+{
+    double o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) o[u] = any_f64_from<CTRL, ROW_MASK>(v[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_fmax(v[u], o[u]);
+}
+template <int U>
+PSK_DEV void any_max_f64_multi(double (&v)[U])
+{
+    any_max_f64_level<0x111, 0xF>(v);
+    any_max_f64_level<0x112, 0xF>(v);
+    any_max_f64_level<0x114, 0xF>(v);
+    any_max_f64_level<0x118, 0xF>(v);
+    any_max_f64_level<0x142, 0xA>(v);
+    any_max_f64_level<0x143, 0xC>(v);
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = read_lane(v[u], 63);
+}
 template <int CTRL, int ROW_MASK>
 PSK_DEV unsigned any_u32_from(unsigned v)
 {
@@ -115,6 +137,27 @@ PSK_DEV unsigned any_min_u32(unsigned v)
     o = any_u32_from<0x142, 0xA>(v), v = o < v ? o : v;
     o = any_u32_from<0x143, 0xC>(v), v = o < v ? o : v;
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK, int U>
+PSK_DEV void any_min_u32_level(unsigned (&v)[U])
+{
+    unsigned o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) o[u] = any_u32_from<CTRL, ROW_MASK>(v[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = o[u] < v[u] ? o[u] : v[u];
+}
+template <int U>
+PSK_DEV void any_min_u32_multi(unsigned (&v)[U])
+{
+    any_min_u32_level<0x111, 0xF>(v);
+    any_min_u32_level<0x112, 0xF>(v);
+    any_min_u32_level<0x114, 0xF>(v);
+    any_min_u32_level<0x118, 0xF>(v);
+    any_min_u32_level<0x142, 0xA>(v);
+    any_min_u32_level<0x143, 0xC>(v);
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = (unsigned)__builtin_amdgcn_readlane((int)v[u], 63);
 }
 // NP: phases a lane holds at most (samplesPerBaud <= 64 * NP for every channel of the launch).  With one phase a lane (NP = 1,
 // samplesPerBaud <= 64) the energies entering and leaving the window are asked for eight symbols at a time: the walk is one
@@ -146,7 +189,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     X.L0 = p.ring_len0;
     const int S = (int)p.S, A = (int)p.A;
     const uint32_t M = p.M;
-    const int nk = (S + kWave - 1) / kWave;
+    const int nk = NP == 1 ? 1 : (S + kWave - 1) / kWave;  // (a compile-time 1 where it can be: no branches inside the symbol step)
     const bool timing = S > 1;  // (samplesPerBaud == 1: a symbol per sample, nothing to pick, cpp/psk_soft.cpp:468-469)
     const AtanTabDev atab = atan_tab_dev(lane);
     float *raw_row = t_raw + p.tile_off;
@@ -173,11 +216,22 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
         return e;
     };
     // the window in front of the tile's first symbol: symbols i_begin .. i_begin + numAvg - 2, in order
-    for (long long tau = i_begin; timing && tau < (long long)i_begin + A - 1; tau++) {
+    // (several symbols' loads at a time here too: with numAvg in the thousands this loop is most of a tile)
+    constexpr int UW = NP == 1 ? 8 : NP == 4 ? 4 : 1;
+    const long long tau_end = (long long)i_begin + A - 1;
+    for (long long tau = i_begin; timing && tau < tau_end; tau += UW) {
+        float e[UW][NP];
 #pragma unroll
-        for (int j = 0; j < NP; j++)
-            if (j < nk)
-                W[j] += (double)energy(tau, lane + kWave * j);
+        for (int u = 0; u < UW; u++)
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                e[u][j] = (tau + u < tau_end && j < nk) ? energy(tau + u, lane + kWave * j) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < UW; u++)
+#pragma unroll
+            for (int j = 0; j < NP; j++)
+                if (tau + u < tau_end && j < nk)
+                    W[j] += (double)e[u][j];
     }
     float gap_rel = __builtin_inff(), wmax = 0.0f;
     int kb = 0, k_last = 0;
@@ -196,13 +250,47 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u;
-            if (i >= i_end)
-                break;
-            int kbest = 0;
+        // (no way out of the chunk half-way: one straight run of code lets the steps of its symbols overlap -- each is a long chain of
+        // dependent reductions, and only the two additions to the sums tie a step to the one before.  Symbols past the end of
+        // the tile add zeros and leave nothing behind.)
+        if constexpr (NP == 1) {
             if (timing) {
+                // one phase a lane: the sums of the chunk's symbols first (two additions a symbol, in order), then the three
+                // reductions for all of them level by level, then the bookkeeping in order
+                double best[U], second[U];
+                unsigned k_win[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    W[0] += (double)e_in[u][0];  // the newest symbol of the window arrives
+                    best[u] = lane < S ? W[0] : -__builtin_inf();
+                    W[0] -= (double)e_out[u][0];  // the oldest leaves
+                    second[u] = best[u];
+                }
+                any_max_f64_multi(best);
+#pragma unroll
+                for (int u = 0; u < U; u++) k_win[u] = second[u] == best[u] ? (unsigned)lane : 0xFFFFFFFFu;  // (std::max_element, cpp/psk_soft.cpp:462: the first)
+                any_min_u32_multi(k_win);
+#pragma unroll
+                for (int u = 0; u < U; u++) second[u] = (unsigned)lane == k_win[u] ? -__builtin_inf() : second[u];
+                any_max_f64_multi(second);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int i = i0 + u;
+                    const bool live = i < i_end;
+                    const int kbest = (int)k_win[u];
+                    k_last = live ? kbest : k_last;
+                    wmax = live ? __builtin_fmaxf(wmax, (float)best[u] * 1.0000002f) : wmax;
+                    const float g = (float)(best[u] - second[u]) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
+                    const float gap_new = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
+                    gap_rel = live ? gap_new : gap_rel;
+                    kb = (live && lane == (i & (kWave - 1))) ? kbest : kb;  // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+                }
+            }
+        } else if (timing) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u;
+                const bool live = U == 1 || i < i_end;
                 // the newest symbol of the window arrives
 #pragma unroll
                 for (int j = 0; j < NP; j++)
@@ -229,20 +317,21 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                 const double best = any_max_f64(top.best);
                 const unsigned k_win = any_min_u32(top.best == best ? (unsigned)top.k : 0xFFFFFFFFu);
                 const double second = any_max_f64((unsigned)top.k == k_win ? top.second : top.best);
-                kbest = (int)k_win;
-                k_last = kbest;
+                const int kbest = (int)k_win;
+                k_last = live ? kbest : k_last;
                 const float best_f = (float)best;
-                wmax = __builtin_fmaxf(wmax, best_f * 1.0000002f);
+                wmax = live ? __builtin_fmaxf(wmax, best_f * 1.0000002f) : wmax;
                 const float g = (float)(best - second) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
-                gap_rel = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
+                const float gap_new = (g < gap_rel) ? g : ((g == g) ? gap_rel : 0.0f);
+                gap_rel = live ? gap_new : gap_rel;
                 // the oldest symbol of the window leaves
 #pragma unroll
                 for (int j = 0; j < NP; j++)
                     if (j < nk)
                         W[j] -= (double)(U > 1 ? e_out[u][j] : energy(i, lane + kWave * j));
+                // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
+                kb = (live && lane == (i & (kWave - 1))) ? kbest : kb;
             }
-            // the pick (cpp/psk_soft.cpp:465) waits in lane (i mod 64)
-            kb = lane == (i & (kWave - 1)) ? kbest : kb;
         }
         // (tiles start on block boundaries and U divides 64: a group of 64 picks ends with a chunk)
         const int i = (i0 + U < i_end ? i0 + U : i_end) - 1;

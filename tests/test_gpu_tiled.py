@@ -331,6 +331,8 @@ ANY_CASES = [
     (4, 24, 0, 600, 50, 24 * 4000, 24 * 1500),
     (4, 100, 0, 30, 10, 100 * 1500, 100 * 500 + 3),
     (4, 1024, 0, 3, 5, 1024 * 300, None),
+    (4, 200, 0, 100, 50, 200 * 1500, 200 * 700 + 11),  # four phases a lane, a window of several tiles' length
+    (2, 300, 1, 17, 10, 300 * 900, None),             # sixteen phases a lane
     (4, 1, 0, 0, 50, 20000, 7001),    # samplesPerBaud 1 with numAvg 0: a symbol per sample, no timing recovery (quirk Q11)
     (8, 1, 1, 0, 200, 30000, None),
     (2, 1, 0, 0, 3, 5000, 64),
