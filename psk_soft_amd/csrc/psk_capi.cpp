@@ -625,9 +625,14 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         // reference-order kernel; a tile at least as long as the longest window, so that rebuilding it stays a fraction)
         uint64_t K = res.blocks_any / kTiledTargetTiles;
         K = K < 2 ? 2 : K > 16 ? 16 : K;
+        // (a tile rebuilds the window in front of it: tiles at least as long as the longest window keep that a fraction of the
+        // work -- where there are tiles enough to fill the machine anyway; a few channels finish sooner on many short tiles)
         const uint64_t k_win = (res.max_A_any + 127u) / 128u;
-        if (K < k_win)
-            K = k_win > 64 ? 64 : k_win;
+        if (K < k_win) {
+            const uint64_t k_fill = res.blocks_any / (kTiledTargetTiles / 2);
+            const uint64_t k_long = k_win > 64 ? 64 : k_win;
+            K = k_fill > k_long ? k_long : k_fill > K ? k_fill : K;
+        }
         tiles_max_any = (uint32_t)((res.max_blocks_any + K - 1) / K);
         for (uint32_t i = 0; i < res.cnt_any; i++) {
             psk::ChanPlan &p = plans[h_list[off_any + i]];
