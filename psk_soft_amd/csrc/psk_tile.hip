@@ -202,10 +202,8 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     bool refuse = false;
     float emax = 0.0f;
     // energy of sample `k` of symbol `tau` (0 past the symbol's end), with the guard's bookkeeping
-    auto energy = [&](long long tau, int k) -> float {
-        if (k >= S)
-            return 0.0f;
-        const float2 v = x_at(X, (uint64_t)tau * (uint64_t)S + (uint64_t)k);
+    auto energy_at = [&](uint64_t j) -> float {  // of sample j of the call's stream
+        const float2 v = x_at(X, j);
         const float e = norm_f(v.x, v.y);
         const unsigned eb = __float_as_uint(e);
         if (eb >= 0x7F800000u)
@@ -215,11 +213,37 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
         emax = __builtin_fmaxf(emax, e);
         return e;
     };
+    auto energy = [&](long long tau, int k) -> float {
+        return k < S ? energy_at((uint64_t)tau * (uint64_t)S + (uint64_t)k) : 0.0f;
+    };
     // the window in front of the tile's first symbol: symbols i_begin .. i_begin + numAvg - 2, in order
     // (several symbols' loads at a time here too: with numAvg in the thousands this loop is most of a tile)
     constexpr int UW = NP == 1 ? 8 : NP == 4 ? 4 : 1;
     const long long tau_end = (long long)i_begin + A - 1;
-    for (long long tau = i_begin; timing && tau < tau_end; tau += UW) {
+    // One phase a lane: the window's samples come in through LDS, 512 at a time with every lane loading (a lane a phase would
+    // leave most of the wave idle for narrow symbols, and wait for memory once per eight symbols); the phases then add their
+    // energies up in order.
+    __shared__ float e_lds[kWave * 8];
+    const bool staged = NP == 1 && timing;
+    if (staged) {
+        const uint64_t j1 = (uint64_t)tau_end * (uint64_t)S;
+        const uint32_t per = (uint32_t)((kWave * 8) / S) * (uint32_t)S;  // whole symbols
+        for (uint64_t jb = (uint64_t)i_begin * (uint64_t)S; jb < j1; jb += per) {
+            const uint32_t len = j1 - jb < per ? (uint32_t)(j1 - jb) : per;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t o = (uint32_t)(lane + kWave * r);
+                e_lds[o] = o < len ? energy_at(jb + o) : 0.0f;
+            }
+            wave_lds_fence();
+            if (lane < S) {
+                const int ns = (int)(len / (uint32_t)S);
+                for (int t = 0; t < ns; t++) W[0] += (double)e_lds[t * S + lane];
+            }
+            wave_lds_fence();
+        }
+    }
+    for (long long tau = i_begin; timing && !staged && tau < tau_end; tau += UW) {
         float e[UW][NP];
 #pragma unroll
         for (int u = 0; u < UW; u++)
