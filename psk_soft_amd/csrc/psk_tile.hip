@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     // One phase a lane: the window's samples come in through LDS, 512 at a time with every lane loading (a lane a phase would
     // leave most of the wave idle for narrow symbols, and wait for memory once per eight symbols); the phases then add their
     // energies up in order.
-    __shared__ float e_lds[kWave * 8];
+    __shared__ float e_lds[kWave * 8], e_lds_out[kWave * 8];
     const bool staged = NP == 1 && timing;
     if (staged) {
         const uint64_t j1 = (uint64_t)tau_end * (uint64_t)S;
@@ -264,14 +264,34 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
     for (int i0 = i_begin; i0 < i_end; i0 += U) {
         float e_in[U][NP], e_out[U][NP];
         if constexpr (U > 1) {
+            // the chunk's symbols entering and leaving the window: two runs of U * samplesPerBaud consecutive samples, loaded by all
+            // the lanes into LDS and read back by the phases (the leaving ones have been through the bookkeeping when they entered)
+            if (timing) {
+                const int nu = i_end - i0 < U ? i_end - i0 : U;
+                const uint32_t len = (uint32_t)(nu * S);
+                const uint64_t j_in = (uint64_t)((long long)i0 + A - 1) * (uint64_t)S, j_out = (uint64_t)i0 * (uint64_t)S;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const bool on = timing && i0 + u < i_end;
-#pragma unroll
-                for (int j = 0; j < NP; j++) {
-                    e_in[u][j] = (on && j < nk) ? energy((long long)(i0 + u) + A - 1, lane + kWave * j) : 0.0f;
-                    e_out[u][j] = (on && j < nk) ? energy(i0 + u, lane + kWave * j) : 0.0f;
+                for (int r = 0; r < 8; r++) {
+                    if ((uint32_t)(kWave * r) >= len)  // (wave-uniform)
+                        break;
+                    const uint32_t o = (uint32_t)(lane + kWave * r);
+                    float ei = 0.0f, eo = 0.0f;
+                    if (o < len) {
+                        ei = energy_at(j_in + o);
+                        const float2 v = x_at(X, j_out + o);
+                        eo = norm_f(v.x, v.y);
+                    }
+                    e_lds[o] = ei;
+                    e_lds_out[o] = eo;
                 }
+                wave_lds_fence();
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const bool on = u < nu && lane < S;
+                    e_in[u][0] = on ? e_lds[u * S + lane] : 0.0f;
+                    e_out[u][0] = on ? e_lds_out[u * S + lane] : 0.0f;
+                }
+                wave_lds_fence();
             }
         }
         // (no way out of the chunk half-way: one straight run of code lets the steps of its symbols overlap -- each is a long chain of
