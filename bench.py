@@ -277,11 +277,16 @@ def launch_ranks(a):
     for p in procs:
         p.wait()
         rc = rc or p.returncode
-    sys.stdout.write(out0)
+    # rank 0's JSON line and nothing else on stdout (what libraries print there -- gloo announces its peers -- goes to stderr)
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    for l in out0.splitlines():
+        if not line or l is not line[-1]:
+            print(l, file=sys.stderr)
+    if line:
+        sys.stdout.write(line[-1] + "\n")
     sys.stdout.flush()
     if rc:
         raise SystemExit("bench.py: a rank failed (exit status %d)" % rc)
-    line = [l for l in out0.splitlines() if l.startswith("{")]
     if not line or json.loads(line[-1]).get("n_gpus") != n:
         raise SystemExit("bench.py: rank 0 did not report %d ranks" % n)
 
