@@ -62,6 +62,12 @@ def parse():
                          "--M 8 --S 10 --strong 32768) instead of --channels per rank")
     ap.add_argument("--serial-classes", action="store_true", help="--mixed: launch the window classes one after the other (A/B of PSK_SOFT_OPT_CONCURRENT_CLASSES)")
     ap.add_argument("--chain-hist", action="store_true", help="per-channel histogram of fit_chain_blocks of the last step (to stderr)")
+    ap.add_argument("--phase0", action="store_true",
+                    help="every channel at zero constellation phase and zero carrier offset (the signal shape of the reference's "
+                         "own test, reference tests/test_psk_soft.py:98-117): LinearFit's sums hover around zero in EVERY channel, "
+                         "the data-dependent worst case of the wave-scan kernel")
+    ap.add_argument("--stamps", default="", metavar="FILE.npy",
+                    help="(diagnostic builds, -DPSK_DIAG_STAMP) save every wave's start / end tick of the last step")
     return ap.parse_args()
 
 
@@ -352,7 +358,7 @@ def main():
             idx = torch.arange(j, C, 3, device=dev)
             iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=0x5EED0000 + rank * 3 + j, cfo_max=a.cfo, sigma=a.sigma, periodic=True)
     else:
-        iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank, cfo_max=a.cfo, sigma=a.sigma, periodic=True)
+        iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED0000 + rank, cfo_max=a.cfo, sigma=a.sigma, periodic=True, phase0=a.phase0)
     if a.scale != 1.0:
         iq *= a.scale
     # output rows start on 128-byte boundaries in all four streams (64 symbols of the narrowest one):
@@ -422,6 +428,19 @@ def main():
         hist = collections.Counter(min(v // 16, 16) for v in cs)
         sys.stderr.write("chain blocks per channel (bins of 16): %s; max %d; channels over 128: %s\n"
                          % (sorted(hist.items()), max(cs), [i for i, v in enumerate(cs) if v > 128][:20]))
+
+    if a.stamps and rank == 0:
+        import struct
+
+        import numpy as np
+
+        st_words = []
+        for c in range(C):
+            blob = h.export_state(c)
+            ctl_bytes = struct.unpack("6I", blob[:24])[4]
+            w = struct.unpack("20I", blob[24 + ctl_bytes: 24 + ctl_bytes + 80])
+            st_words.append((w[19], w[18], w[16], w[17]))  # start tick (or HW_ID), end tick (100 MHz), chained blocks, (XCC_ID)
+        np.save(a.stamps, np.array(st_words, dtype=np.int64))
 
     if use_dist:  # (strong scaling: ranks may own one channel more or less)
         from psk_soft_amd.distributed import sum_over_ranks

@@ -707,7 +707,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 (void)hipGetLastError();
                 for (uint32_t i = 0; i < nch; i++) {
                     if (plans[i].lf_flags & psk::PLAN_ANYFRONT) {  // (no kernel but the reference-order one is left for these)
-                        plans[i].mode = psk::PLAN_SEQ;
+                        plans[i].mode = plans[i].S == 1u ? psk::PLAN_SEQ_S1 : psk::PLAN_SEQ;
                         res.any_seq = true;
                     }
                     plans[i].lf_flags &= ~(uint32_t)(psk::PLAN_TILED | psk::PLAN_PFIT | psk::PLAN_ANYFRONT);

@@ -293,8 +293,11 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         while (cnt > kResyncCount) cnt -= kResyncCount;
         c.lf_count = cnt;
     }
-    if (plan.mode == PLAN_FAST || plan.mode == PLAN_SEQ)
-        c.ring_src ^= 1u;  // these kernels write the surviving samples to the other ring buffer
+    // these kernels write the surviving samples to the other ring buffer -- except at samplesPerBaud == 1, where the reference
+    // leaves the deque alone (cpp/psk_soft.cpp:445: nothing is pushed, nothing popped): the carried samples stay where they
+    // are, whatever the kernels of that call write into the other buffer
+    if ((plan.mode == PLAN_FAST || plan.mode == PLAN_SEQ) && S != 1)
+        c.ring_src ^= 1u;
 
     out.n_symbols = n_out;
     out.n_bits = n_out * bpb;

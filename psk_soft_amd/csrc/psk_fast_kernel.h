@@ -152,6 +152,15 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
         er.mem = ering_s;
     }
     const int lane = threadIdx.x & 63;
+#ifdef PSK_DIAG_STAMP  /* (diagnostic builds only: when each wave started and ended, 100 MHz ticks, into two statistics words) */
+    const uint32_t diag_t0 = (uint32_t)wall_clock64();
+#endif
+#ifdef PSK_STAGGER  /* (experiment: waves of a launch start up to PSK_STAGGER * 0.43 us apart instead of all at once) */
+    if (SV != 0 && !EXACT) {
+        const uint32_t hsh = (blockIdx.x * 2654435761u) >> 24;
+        for (uint32_t i = 0; i < (hsh * (uint32_t)(PSK_STAGGER)) >> 8; i++) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // the launch covers the channels of the batch that this instantiation handles: list[workgroup] = index into the batch
     const uint32_t bi = list[blockIdx.x];
     const ChanPlan &p = plans[bi];
@@ -179,8 +188,11 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
     call_prologue(p, st, yv, fit_cap, yring, ymask, lane, cy);
 
     // ---- the symbol loop ----
-    if constexpr (SV != 0)
+    if constexpr (SV != 0) {
         fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy);
+        if constexpr (PSK_PACE_ON(false, EXACT))
+            pace_post(pace_key(), 0u, lane);  // (on every way out of the loop: nothing left, whoever takes this wave slot next)
+    }
 
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
     //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
@@ -207,6 +219,17 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
     }
 
     call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, EXACT ? 3u : 0u);
+#ifdef PSK_DIAG_STAMP
+    if (lane == 0) {
+#ifdef PSK_DIAG_HWID  /* (where the wave ran: HW_ID (register 4) and XCC_ID (register 20)) */
+        st->stat_pfit = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        st->emax_hint = __uint_as_float((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+#else
+        st->stat_pfit = diag_t0;
+#endif
+        st->pad_state = (uint32_t)wall_clock64();
+    }
+#endif
 }
 
 #define PSK_FAST_ARGS                                                                                          \

@@ -172,6 +172,33 @@ PSK_DEV float2 select_sample(const float2 (&x)[S], int k)
     return make_float2(sel_tree<S, 0, P>(x, k, false), sel_tree<S, 0, P>(x, k, true));
 }
 
+// x[k] for a WAVE-UNIFORM k: a scalar jump table and one move per component instead of the select tree.  (The timing index a
+// lane predicts is the one its symbol had a block ago: on a signal whose timing stands still every lane predicts the same.
+// The empty asm statements keep the compiler from folding the cases back into selects.)
+template <int S>
+PSK_DEV float2 select_sample_uniform(const float2 (&x)[S], int k)
+{
+    float rx = x[0].x, ry = x[0].y;
+    switch (k) {
+#define PSK_SEL_CASE(i)                              \
+    case i:                                          \
+        if constexpr (i < S) {                       \
+            rx = x[i < S ? i : 0].x;                 \
+            ry = x[i < S ? i : 0].y;                 \
+            asm volatile("" : "+v"(rx), "+v"(ry));   \
+        }                                            \
+        break;
+        PSK_SEL_CASE(1) PSK_SEL_CASE(2) PSK_SEL_CASE(3) PSK_SEL_CASE(4) PSK_SEL_CASE(5) PSK_SEL_CASE(6) PSK_SEL_CASE(7)
+        PSK_SEL_CASE(8) PSK_SEL_CASE(9) PSK_SEL_CASE(10) PSK_SEL_CASE(11) PSK_SEL_CASE(12) PSK_SEL_CASE(13) PSK_SEL_CASE(14)
+        PSK_SEL_CASE(15) PSK_SEL_CASE(16) PSK_SEL_CASE(17) PSK_SEL_CASE(18) PSK_SEL_CASE(19) PSK_SEL_CASE(20) PSK_SEL_CASE(21)
+        PSK_SEL_CASE(22) PSK_SEL_CASE(23) PSK_SEL_CASE(24) PSK_SEL_CASE(25) PSK_SEL_CASE(26) PSK_SEL_CASE(27) PSK_SEL_CASE(28)
+        PSK_SEL_CASE(29) PSK_SEL_CASE(30) PSK_SEL_CASE(31)
+#undef PSK_SEL_CASE
+    default: break;
+    }
+    return make_float2(rx, ry);
+}
+
 // loads the two symbols at positions 2*lane, 2*lane+1 of "new-symbol block" cblk:
 // tau = kB*cblk + s + A - 1; symbols outside [tau_lo, tau_hi] are zero-filled.
 //
@@ -423,7 +450,7 @@ PSK_DEV bool odd_f64(double n) { return __builtin_amdgcn_fract(n * 0.5) != 0.0; 
 //     second one, to multiples of 2, is exact for an even r_j + t_j and a state-dependent tie for an odd one.
 // Anything else (intermediates changing binade, operands off the grid, non-finite values) produces
 // candidates that do not verify (returns false).  tools/model/xysum_grid_model.cpp is the CPU model of this.
-PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const double (&t)[kR], double (&xs)[kR])
+PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const double (&t)[kR], double (&xs)[kR], double &xs_prev)
 {
     const double r_first = s_c - read_lane(c[0], 0);          // (wave-uniform, like s_c)
     const int eb = (__double2hiint(r_first) >> 20) & 0x7ff;   // biased exponent of the intermediates' binade
@@ -476,10 +503,19 @@ PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const doubl
         a0 = inc[0] + (T[0] ? (sel0 ? 1.0 : -1.0) : 0.0);
         a1 = inc[1] + (T[1] ? (sel1 ? 1.0 : -1.0) : 0.0);
     }
+    // (integers below 2^53: every sum here is exact, so the lane's second sum may be taken from the scan -- the same expression
+    // the next lane forms for its predecessor: xs_prev IS the previous lane's xs[1], bit for bit, without a cross-lane move)
     const double incl = wave_scan_f64(a0 + a1);
-    const double x0 = (S_c + wave_up1(incl, 0.0)) + a0;
-    xs[0] = x0 * q;
-    xs[1] = (x0 + a1) * q;
+    const double xp = S_c + wave_up1_zero(incl);
+    xs_prev = xp * q;
+    xs[0] = (xp + a0) * q;
+    xs[1] = (S_c + incl) * q;
+}
+
+PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const double (&t)[kR], double (&xs)[kR])
+{
+    double xs_prev;
+    xysum_grid(lane, s_c, c, t, xs, xs_prev);
 }
 
 // The certificate.  Every valid position re-runs the reference's four statements (cpp/psk_soft.cpp:70, :72, :77,
@@ -488,11 +524,12 @@ PSK_DEV void xysum_grid(int lane, double s_c, const double (&c)[kR], const doubl
 // from the block's y and z (cheaper than keeping the candidates' own operands in registers across xysum_grid);
 // where the window is still filling there is no pop (z = 0, and x - 0 is x).  A NaN never verifies (the chain
 // then produces the reference's own).  Returns bit 0: ySum fails, bit 1: xySum fails.
+// ys_prev / xs_prev: the candidates of the position in front of the lane's first one -- the previous lane's second sums, which
+// the candidates' producers form by the same expression as that lane does (the carried sums for lane 0).
 PSK_DEV int fit_sums_verify(const bool (&valid)[kR], const bool (&steady)[kR], float xd, const float (&sizef)[kR],
-                            double ySum_c, double xySum_c, const float (&z)[kR], const float (&y)[kR],
+                            double ys_prev, double xs_prev, const float (&z)[kR], const float (&y)[kR],
                             const double (&ySum_l)[kR], const double (&xySum_l)[kR])
 {
-    const double ys_prev = wave_up1(ySum_l[1], ySum_c), xs_prev = wave_up1(xySum_l[1], xySum_c);
     const double p0 = ys_prev - (double)z[0], p1 = ySum_l[0] - (double)z[1];  // ySum after the pop, :70
     const bool y0 = p0 + (double)y[0] == ySum_l[0], y1 = p1 + (double)y[1] == ySum_l[1];
     const double c0 = steady[0] ? (double)xd * p0 : 0.0, c1 = steady[1] ? (double)xd * p1 : 0.0;  // :72
@@ -642,12 +679,14 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             z[r] = steady[r] ? yring[(before[r] - n) & ymask] : 0.0f;  // yvals.front(), :70
         wave_lds_fence();
         // candidate sums, wave-parallel (positions past the end need no masking: a prefix sum never looks ahead)
+        double ys_prev, xs_prev;
         {
             const double dy0 = (double)y[0] - (double)z[0], dy1 = (double)y[1] - (double)z[1];
             const double incl = wave_scan_f64(dy0 + dy1);
-            const double base = cy.ySum + wave_up1(incl, 0.0);  // ySum after the previous lane's symbols
+            const double base = cy.ySum + wave_up1_zero(incl);  // ySum after the previous lane's symbols
             ySum_l[0] = base + dy0;
-            ySum_l[1] = ySum_l[0] + dy1;
+            ySum_l[1] = cy.ySum + incl;  // (the expression the next lane calls `base`: the certificate's chain needs no move)
+            ys_prev = base;
             // xdelta*ySum after the pop, :70 and :72
             const double c_d[kR] = {steady[0] ? (double)xd * (base - (double)z[0]) : 0.0,
                                     steady[1] ? (double)xd * (ySum_l[0] - (double)z[1]) : 0.0};
@@ -660,14 +699,15 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
                 // (the caller runs the recurrence for xySum over this block anyway: any guess will do here)
                 const double cc0 = t_d[0] - c_d[0], cc1 = t_d[1] - c_d[1];
                 const double i2 = wave_scan_f64(cc0 + cc1);
-                const double b2 = cy.xySum + wave_up1(i2, 0.0);
+                const double b2 = cy.xySum + wave_up1_zero(i2);
                 xySum_l[0] = b2 + cc0;
                 xySum_l[1] = xySum_l[0] + cc1;
+                xs_prev = b2;
             } else {
-                xysum_grid(lane, cy.xySum, c_d, t_d, xySum_l);
+                xysum_grid(lane, cy.xySum, c_d, t_d, xySum_l, xs_prev);
             }
         }
-        int rej = WARM ? 3 : fit_sums_verify(valid, steady, xd, sizef, cy.ySum, cy.xySum, z, y, ySum_l, xySum_l);
+        int rej = WARM ? 3 : fit_sums_verify(valid, steady, xd, sizef, ys_prev, xs_prev, z, y, ySum_l, xySum_l);
         if (cheap)
             rej |= 2;
         rejected = rej;
@@ -696,8 +736,20 @@ PSK_DEV int fit_block(int lane, uint32_t q0, uint32_t n, float xd, float den_s, 
             if (__all(sure0 && sure1))
                 break;
         }
-        WInt w2_0 = (WInt)unwrap_count(est_prev0, (double)raw[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
-        WInt w2_1 = (WInt)unwrap_count(est[0], (double)raw[1], (int)q0);
+        const long long c2_0 = unwrap_count(est_prev0, (double)raw[0], (int)q0);  // cpp/psk_soft.cpp:477 with the true feedback
+        const long long c2_1 = unwrap_count(est[0], (double)raw[1], (int)q0);
+        if constexpr (!WIDE) {
+            // a count beyond 32 bits -- the feedback is NaN ((long)NaN is LONG_MIN on x86) or astronomically large, what a
+            // non-finite sample leaves behind in a channel -- is the exact tier's, which keeps the counts in 64 bits: truncated,
+            // LONG_MIN would pass for 0 and a wrong count could be taken for verified
+            const bool wide0 = valid[0] && c2_0 != (long long)(int)c2_0, wide1 = valid[1] && c2_1 != (long long)(int)c2_1;
+            if (__any(wide0 || wide1)) {
+                pass = kMaxUnwrapPasses + 1;  // (the caller refuses the call)
+                break;
+            }
+        }
+        WInt w2_0 = (WInt)c2_0;
+        WInt w2_1 = (WInt)c2_1;
         const bool bad = (valid[0] && w2_0 != w[0]) || (valid[1] && w2_1 != w[1]);
         if (!__any(bad))
             break;
@@ -1079,6 +1131,48 @@ PSK_DEV void output_stage(const ChanPlan &p, int c, int i0, const bool (&valid)[
     }
 }
 
+#ifndef PSK_SELECT_UNIFORM
+#define PSK_SELECT_UNIFORM 1
+#endif
+// ---- paced priorities: see fast_main_loop ----
+#ifndef PSK_PACE
+#define PSK_PACE 1
+#endif
+#define PSK_PACE_ON(FRONT_, EXACT_) (PSK_PACE != 0 && !(FRONT_) && !(EXACT_))
+constexpr int kPaceRows = 2048, kPaceSlots = 8;  // rows: XCC (3 bits) : SE (2) : CU (4) : SIMD (2); slots: WAVE_ID
+// (one table per translation unit, i.e. per instantiation of the kernel: waves of different kernels that meet on a SIMD do
+// not see one another -- they just keep the hardware's oldest-first order among themselves)
+static __device__ uint32_t g_pace_table[kPaceRows * kPaceSlots];
+// this wave's place in the table: word index of its SIMD's row, and its slot in the row (bits 16 ..)
+PSK_DEV uint32_t pace_key()
+{
+    const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: WAVE_ID [3:0] SIMD_ID [5:4] CU_ID [11:8] SE_ID [15:13]
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID [3:0]
+    const uint32_t r = ((xcc & 7u) << 8) | (((hw >> 13) & 3u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+    return (r * (uint32_t)kPaceSlots) | ((hw & 7u) << 16);
+}
+// the row, past the vector cache (sc1: the other waves' stores sit in the XCD's L2): the lane's word (lanes 0 .. 7)
+PSK_DEV uint32_t pace_fetch(uint32_t key, int lane)
+{
+    uint32_t v = 0u;
+    if (lane < kPaceSlots)
+        v = __hip_atomic_load(g_pace_table + (key & 0xffffu) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+// publishes the blocks this wave has left (0 = gone)
+PSK_DEV void pace_post(uint32_t key, uint32_t left, int lane)
+{
+    if (lane == 0)
+        __hip_atomic_store(g_pace_table + (key & 0xffffu) + (key >> 16), left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// priority by rank: 3 for the wave with the most blocks left on its SIMD, one less for every neighbour that has more
+PSK_DEV int pace_rank(uint32_t key, uint32_t row_word, uint32_t left, int lane)
+{
+    const unsigned long long more = __builtin_amdgcn_ballot_w64(lane < kPaceSlots && lane != (int)(key >> 16) && row_word > left);
+    const int ahead = __builtin_popcountll(more);
+    return ahead >= 3 ? 0 : 3 - ahead;
+}
+
 // FRONT = true is the first stage of the time-tiled kernels (psk_tile_kernel.h): the same loop over the blocks
 // [c_begin, c_end) of the call -- its window rebuilt from the numAvg - 1 symbols in front of block c_begin exactly as
 // the call's first window is rebuilt from the carried samples --, stopping after the raw phase: the picked samples
@@ -1174,14 +1268,42 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     if constexpr (H == 1)
         ering_put<S>(er, er.length() - kB, lane, hist[0].e);  // block -1
 
+    // ---- paced priorities (PSK_PACE) ----
+    // The four waves that share a SIMD are issued oldest first: left to itself the first-dispatched wave of a SIMD runs a
+    // fifth faster than the last (measured on the headline: the four dispatch quarters of a launch end at 1.95 / 2.06 /
+    // 2.21 / 2.37 ms), and from the moment the oldest waves retire the SIMDs run with three, two, one wave -- a launch lasts
+    // as long as its youngest waves while the machine idles behind the others.  Every wave therefore publishes the blocks it
+    // has LEFT in a table in global memory, one row per SIMD (found from HW_ID / XCC_ID) and one word per wave slot, reads the
+    // row once a block, and takes the priority of its rank: most work left, highest priority.  The waves of a SIMD then
+    // advance together and end together, whatever slows one of them down (an older neighbour, blocks that need the
+    // lane-after-lane chain, exact timing redos).  Priorities change no result; stale or missing table entries only cost speed.
+    uint32_t pace = 0u;
+    if constexpr (PSK_PACE_ON(FRONT, EXACT))
+        pace = pace_key();
+    auto set_prio_dyn = [](int v) {
+        switch (v) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
     for (int c = c_begin; c < n_blocks; c++) {
-        // the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
+        // Without pacing: the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
         // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %, touching the next block's
         // lines with a one-dword load per lane half a block ahead +9 %: the loads in flight are not the limit)
-        __builtin_amdgcn_s_setprio(3);
+        if constexpr (!PSK_PACE_ON(FRONT, EXACT))
+            __builtin_amdgcn_s_setprio(3);
+        uint32_t pace_row = 0u;
+        if constexpr (PSK_PACE_ON(FRONT, EXACT))
+            pace_row = pace_fetch(pace, lane);  // (in front of the block's loads: it is back before they are)
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+        if constexpr (PSK_PACE_ON(FRONT, EXACT)) {
+            pace_post(pace, (uint32_t)(n_blocks - c), lane);  // (behind them: nothing waits for a store)
+            set_prio_dyn(pace_rank(pace, pace_row, (uint32_t)(n_blocks - c), lane));
+        }
 
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
         bool valid[kR];
@@ -1206,7 +1328,16 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 cur.e[r][k] = e;
             }
             cur.kp[r] = kpred[r];
-            cur.pk[r] = select_sample<S>(xn[r], kpred[r]);
+        }
+        {
+            const int k0u = __builtin_amdgcn_readfirstlane(kpred[0]), k1u = __builtin_amdgcn_readfirstlane(kpred[1]);
+            if (PSK_SELECT_UNIFORM && vote_all(kpred[0] == k0u && kpred[1] == k1u)) {
+                cur.pk[0] = select_sample_uniform<S>(xn[0], k0u);
+                cur.pk[1] = select_sample_uniform<S>(xn[1], k1u);
+            } else {
+                cur.pk[0] = select_sample<S>(xn[0], kpred[0]);
+                cur.pk[1] = select_sample<S>(xn[1], kpred[1]);
+            }
         }
         // energy of symbol i-1 for every phase (it entered the window A symbols before symbol
         // i+A-1 did): all cross-lane fetches issued back to back
@@ -1412,7 +1543,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         // ~2 us of pure latency per block there.  The launch waits for its slowest wave, so such a wave keeps a
         // raised priority through the arithmetic half too: its other work then runs ahead of its neighbours'
         // and the wave keeps pace with them.  There are a handful of them in thousands.)
-        if (cy.chain_streak >> 16)
+        if constexpr (PSK_PACE_ON(FRONT, EXACT)) {
+        } else if (cy.chain_streak >> 16)
             __builtin_amdgcn_s_setprio(PSK_CHAIN_PRIO);
         else
             __builtin_amdgcn_s_setprio(0);

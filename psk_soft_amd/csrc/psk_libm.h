@@ -319,10 +319,11 @@ PSK_HD float lm_atan2f_ordinary_t(float y, float x, bool *special, const Tab &ta
     const float p = t * (s1 + s2);
     float zat = hi - ((p - lo) - t);  // atanf(|y/x|)
     // quadrant, e_atan2f.c switch (m); x == 1.0 needs no case of its own: atanf(y) is odd in y
+    // (x - y and y - x round to the same magnitude: the lower half plane is the upper one with the sign of y -- one select
+    // and one sign transfer instead of two differences and three selects)
     const bool xneg = (ux >> 31) != 0, yneg = (uy >> 31) != 0;
     float q2 = pi - (zat - pi_lo);
-    float q3 = (zat - pi_lo) - pi;
-    float r = xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+    float r = lm_asfloat((lm_asuint(xneg ? q2 : zat) & 0x7fffffffu) | (uy & 0x80000000u));
     // rare operands, patched afterwards:
     //  * a >= 2^25 (also a = inf): s_atanf.c returns hi3 + lo3, and e_atan2f.c's shortcut for an
     //    exponent difference above 60, pi/2 + 0.5*pi_lo, is the same float.  (Its other shortcut,
@@ -332,8 +333,7 @@ PSK_HD float lm_atan2f_ordinary_t(float y, float x, bool *special, const Tab &ta
     if (tab.any(rare)) {
         zat = (ia >= 0x4c000000u) ? pi_o_2 : zat;
         q2 = pi - (zat - pi_lo);
-        q3 = (zat - pi_lo) - pi;
-        r = xneg ? (yneg ? q3 : q2) : (yneg ? -zat : zat);
+        r = lm_asfloat((lm_asuint(xneg ? q2 : zat) & 0x7fffffffu) | (uy & 0x80000000u));
         const float ry0 = xneg ? (yneg ? -pi : pi) : y;
         const float rx0 = yneg ? -pi_o_2 : pi_o_2;
         r = (ix == 0) ? rx0 : r;

@@ -128,6 +128,13 @@ PSK_DEV double wave_up1(double v, double carry)
     int hi = wave_up1(__double2hiint(v), __double2hiint(carry));
     return __hiloint2double(hi, lo);
 }
+// ... lane 0 receives zero (bound_ctrl: no register has to be preloaded with the carry -- two moves less per double)
+PSK_DEV int wave_up1_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+PSK_DEV float wave_up1_zero(float v) { return __int_as_float(wave_up1_zero(__float_as_int(v))); }
+PSK_DEV double wave_up1_zero(double v)
+{
+    return __hiloint2double(wave_up1_zero(__double2hiint(v)), wave_up1_zero(__double2loint(v)));
+}
 PSK_DEV float read_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 PSK_DEV double read_lane(double v, int lane)
 {

@@ -95,12 +95,16 @@ def synth_channels(channels, M, S, n_complex, **kw):
 
 
 def synth_channels_torch(n_channels, M, S, n_complex, device, sigma=0.01, cfo_max=1e-3, seed=SEED_BASE,
-                         chunk_channels=256, periodic=False):
+                         chunk_channels=256, periodic=False, phase0=False):
     """Same workload, generated on the GPU with torch ops (bench sizes: GiBs of I/Q).
     Returns a [n_channels, 2*n_complex] float32 tensor on `device`.
     periodic=True rounds every channel's carrier offset to the nearest value whose phase advance over
     the buffer is a multiple of 2*pi/M, so that feeding the same buffer again and again (as bench.py
-    does) is one continuous stream for the carrier loop instead of a phase jump per call."""
+    does) is one continuous stream for the carrier loop instead of a phase jump per call.
+    phase0=True: every channel's constellation sits at zero phase with no carrier offset -- the signal
+    shape of the reference's own component test (reference tests/test_psk_soft.py:98-117: ideal
+    constellation points, no offset), with this workload's pulse, gains and noise.  The M-th-power phase
+    is then noise around zero and LinearFit's running sums hover around zero in every channel."""
     import torch
 
     gen = torch.Generator(device=device)
@@ -115,6 +119,9 @@ def synth_channels_torch(n_channels, M, S, n_complex, device, sigma=0.01, cfo_ma
         phi0 = torch.rand((nc, 1), generator=gen, device=device) * (2 * math.pi / M)
         gain = 0.5 + 1.5 * torch.rand((nc, 1), generator=gen, device=device)
         dphi = (2 * torch.rand((nc, 1), generator=gen, device=device) - 1) * (cfo_max / M)
+        if phase0:
+            phi0 = phi0 * 0.0
+            dphi = dphi * 0.0
         if periodic and n_complex % S == 0:
             q = 2 * math.pi / (M * n_sym)
             dphi = torch.round(dphi / q) * q

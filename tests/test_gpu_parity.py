@@ -696,6 +696,36 @@ def test_property_changes_mid_stream(oracle_mod):
     h.close()
 
 
+@pytest.mark.parametrize("path", ["tiled", "reference_order", "handed_over"])
+def test_samples_per_baud_1_leaves_the_carried_window_alone(oracle_mod, path):
+    """samplesPerBaud == 1 EMITTING with numAvg > 0 (the window a resyncEnergy trimmed to numAvg samples, index 0): the
+    reference pushes and pops nothing there (cpp/psk_soft.cpp:445, :468-469), so the samples carried from the earlier
+    samplesPerBaud = 8 regime must still be the deque's content when a wider window is configured again -- its first
+    timing picks are made from them.  Through the time-tiled kernels' run-time front stage, through the
+    reference-order kernel, and through the hand-over from the one to the other (a NaN sample in the S == 1 call)."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    iq = synth_channel(77, 4, 8, 30000)
+    nanpkt = iq[2 * 9000 : 2 * 9600].copy()
+    if path == "handed_over":
+        nanpkt[2 * 300] = np.nan
+    script = [
+        ("set", "samplesPerBaud", 8), ("set", "constelationSize", 4), ("set", "numAvg", 100), ("set", "phaseAvg", 50),
+        ("push", iq[: 2 * 9000], dict(sriChanged=True)),
+        ("set", "samplesPerBaud", 1), ("set", "numAvg", 50),
+        ("push", nanpkt, {}),                                   # emits 600 symbols, one per sample; the deque keeps its 50
+        ("push", iq[2 * 9600 : 2 * 10000], {}),
+        ("set", "samplesPerBaud", 8), ("set", "numAvg", 100),
+        ("push", iq[2 * 10000 : 2 * 20000], {}),                # the window refills behind the 50 carried samples
+        ("push", iq[2 * 20000 : 2 * 30000], {}),
+    ]
+    h = _handle(max_window_samples=4096, max_phase_avg=256)
+    if path == "reference_order":
+        h.set_force_sequential(1)
+    _replay(oracle_mod, h, script)
+    h.close()
+
+
 def test_call_longer_than_resync_count(oracle_mod):
     """More than 1048576 symbols in ONE call: the reference resyncs symbolEnergy and the fit sums
     in mid-loop (cpp/psk_soft.cpp:51-52, 582-583); such calls go to the reference-order kernel."""
