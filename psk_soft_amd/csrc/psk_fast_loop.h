@@ -1139,6 +1139,9 @@ PSK_DEV void output_stage(const ChanPlan &p, int c, int i0, const bool (&valid)[
 #define PSK_PACE 1
 #endif
 #define PSK_PACE_ON(FRONT_, EXACT_) (PSK_PACE != 0 && !(FRONT_) && !(EXACT_))
+#ifndef PSK_PACE_EVERY
+#define PSK_PACE_EVERY 4  /* blocks between two looks at the table (a power of two): every block 2.57 ms, every second 2.39, every fourth 2.37, never 2.44 (headline, one box) */
+#endif
 constexpr int kPaceRows = 2048, kPaceSlots = 8;  // rows: XCC (3 bits) : SE (2) : CU (4) : SIMD (2); slots: WAVE_ID
 // (one table per translation unit, i.e. per instantiation of the kernel: waves of different kernels that meet on a SIMD do
 // not see one another -- they just keep the hardware's oldest-first order among themselves)
@@ -1296,11 +1299,12 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if constexpr (!PSK_PACE_ON(FRONT, EXACT))
             __builtin_amdgcn_s_setprio(3);
         uint32_t pace_row = 0u;
-        if constexpr (PSK_PACE_ON(FRONT, EXACT))
+        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && (c & (PSK_PACE_EVERY - 1)) == 0;  // (wave-uniform)
+        if (pace_now)
             pace_row = pace_fetch(pace, lane);  // (in front of the block's loads: it is back before they are)
         float2 xn[kR][S];
         load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
-        if constexpr (PSK_PACE_ON(FRONT, EXACT)) {
+        if (pace_now) {
             pace_post(pace, (uint32_t)(n_blocks - c), lane);  // (behind them: nothing waits for a store)
             set_prio_dyn(pace_rank(pace, pace_row, (uint32_t)(n_blocks - c), lane));
         }

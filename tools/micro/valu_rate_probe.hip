@@ -149,6 +149,42 @@ __global__ __launch_bounds__(64, 4) void k_rate(int iters, unsigned long long *c
                 asm volatile("v_mul_f32 %0, 0x3f800347, %0\n\tv_mul_f32 %1, 0x3f800347, %1\n\tv_mul_f32 %2, 0x3f800347, %2\n\tv_mul_f32 %3, 0x3f800347, %3\n\t"
                              "v_mul_f32 %4, 0x3f800347, %4\n\tv_mul_f32 %5, 0x3f800347, %5\n\tv_mul_f32 %6, 0x3f800347, %6\n\tv_mul_f32 %7, 0x3f800347, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            if (KIND == 43) REP8_2OP("v_add_f32", a0, a1, a2, a3, a4, a5, a6, a7, b);  // placeholder: identical to kind 1
+            if (KIND == 44)  // VOP2 f32 with a scalar-register operand
+                asm volatile("v_add_f32 %0, s20, %0\n\tv_add_f32 %1, s20, %1\n\tv_add_f32 %2, s20, %2\n\tv_add_f32 %3, s20, %3\n\t"
+                             "v_add_f32 %4, s20, %4\n\tv_add_f32 %5, s20, %5\n\tv_add_f32 %6, s20, %6\n\tv_add_f32 %7, s20, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20");
+            if (KIND == 45)  // VOP3 f32 fma, vector registers and an inline constant
+                asm volatile("v_fma_f32 %0, %0, %8, 0.5\n\tv_fma_f32 %1, %1, %8, 0.5\n\tv_fma_f32 %2, %2, %8, 0.5\n\tv_fma_f32 %3, %3, %8, 0.5\n\t"
+                             "v_fma_f32 %4, %4, %8, 0.5\n\tv_fma_f32 %5, %5, %8, 0.5\n\tv_fma_f32 %6, %6, %8, 0.5\n\tv_fma_f32 %7, %7, %8, 0.5"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            if (KIND == 46)  // VOP3 f32 add with the clamp modifier
+                asm volatile("v_add_f32_e64 %0, %0, %8 clamp\n\tv_add_f32_e64 %1, %1, %8 clamp\n\tv_add_f32_e64 %2, %2, %8 clamp\n\tv_add_f32_e64 %3, %3, %8 clamp\n\t"
+                             "v_add_f32_e64 %4, %4, %8 clamp\n\tv_add_f32_e64 %5, %5, %8 clamp\n\tv_add_f32_e64 %6, %6, %8 clamp\n\tv_add_f32_e64 %7, %7, %8 clamp"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            if (KIND == 47)  // VOP3 f32 add with |.| and negation modifiers
+                asm volatile("v_add_f32_e64 %0, |%0|, -%8\n\tv_add_f32_e64 %1, |%1|, -%8\n\tv_add_f32_e64 %2, |%2|, -%8\n\tv_add_f32_e64 %3, |%3|, -%8\n\t"
+                             "v_add_f32_e64 %4, |%4|, -%8\n\tv_add_f32_e64 %5, |%5|, -%8\n\tv_add_f32_e64 %6, |%6|, -%8\n\tv_add_f32_e64 %7, |%7|, -%8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            if (KIND == 48)  // f64 fma with a scalar pair operand
+                asm volatile("v_fma_f64 %0, %0, s[20:21], %8\n\tv_fma_f64 %1, %1, s[20:21], %8\n\tv_fma_f64 %2, %2, s[20:21], %8\n\tv_fma_f64 %3, %3, s[20:21], %8\n\t"
+                             "v_fma_f64 %4, %4, s[20:21], %8\n\tv_fma_f64 %5, %5, s[20:21], %8\n\tv_fma_f64 %6, %6, s[20:21], %8\n\tv_fma_f64 %7, %7, s[20:21], %8"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(f) : "s20", "s21");
+            if (KIND == 49)  // integer add with a scalar operand
+                asm volatile("v_add_u32 %0, s20, %0\n\tv_add_u32 %1, s20, %1\n\tv_add_u32 %2, s20, %2\n\tv_add_u32 %3, s20, %3\n\t"
+                             "v_add_u32 %4, s20, %4\n\tv_add_u32 %5, s20, %5\n\tv_add_u32 %6, s20, %6\n\tv_add_u32 %7, s20, %7"
+                             : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : : "s20");
+            if (KIND == 50)  // move from a scalar register
+                asm volatile("v_mov_b32 %0, s20\n\tv_mov_b32 %1, s20\n\tv_mov_b32 %2, s20\n\tv_mov_b32 %3, s20\n\tv_mov_b32 %4, s20\n\tv_mov_b32 %5, s20\n\tv_mov_b32 %6, s20\n\tv_mov_b32 %7, s20"
+                             : "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3), "=v"(i4), "=v"(i5), "=v"(i6), "=v"(i7) : : "s20");
+            if (KIND == 51) REP8_2OP("v_ashrrev_i32", i0, i1, i2, i3, i4, i5, i6, i7, lane);
+            if (KIND == 52) REP8_2OP("v_sub_u32", i0, i1, i2, i3, i4, i5, i6, i7, lane);
+            if (KIND == 53)
+                asm volatile("v_cvt_i32_f32 %0, %8\n\tv_cvt_i32_f32 %1, %9\n\tv_cvt_i32_f32 %2, %10\n\tv_cvt_i32_f32 %3, %11\n\t"
+                             "v_cvt_i32_f32 %4, %12\n\tv_cvt_i32_f32 %5, %13\n\tv_cvt_i32_f32 %6, %14\n\tv_cvt_i32_f32 %7, %15"
+                             : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7)
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            if (KIND == 54) REP8_1OP("v_rndne_f32", a0, a1, a2, a3, a4, a5, a6, a7);
             if (KIND == 17)  // the kernel's mix: two f32 to one f64
                 asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %6, %7\n\t"
                              "v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f64 %3, %3, %6, %7\n\tv_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5"
@@ -239,6 +275,17 @@ int main()
         run<40>("v_fma_f32 v, s, const", nw);
         run<41>("v_add_f64 v, s[2]", nw);
         run<42>("v_mul_f32 literal", nw);
+        run<44>("v_add_f32 v, s, v", nw);
+        run<45>("v_fma_f32 v,v,v,0.5", nw);
+        run<46>("v_add_f32 clamp", nw);
+        run<47>("v_add_f32 |a|, -b", nw);
+        run<48>("v_fma_f64 v,v,s[2],v", nw);
+        run<49>("v_add_u32 v, s, v", nw);
+        run<50>("v_mov_b32 v, s", nw);
+        run<51>("v_ashrrev_i32", nw);
+        run<52>("v_sub_u32", nw);
+        run<53>("v_cvt_i32_f32", nw);
+        run<54>("v_rndne_f32", nw);
     }
     return 0;
 }
