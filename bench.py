@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-check", dest="check", action="store_false")
     ap.add_argument("--no-few", dest="no_few", action="store_true",
                     help="skip the one-channel measurement (BASELINE configs[1]) that the default run appends as `few_channels`")
+    ap.add_argument("--no-extra", dest="no_extra", action="store_true",
+                    help="skip the other configurations the default single-GPU run appends to its line (`configs3_per_gpu`, `mixed`, "
+                         "`worst_case`, `few_channels_64` / `_512`, `end_to_end`), each measured like the headline with its own oracle check")
     ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_CHANNELS",
                     help="strong scaling: TOTAL_CHANNELS channels shared by the ranks (BASELINE configs[3]: "
                          "--M 8 --S 10 --strong 32768) instead of --channels per rank")
@@ -192,13 +195,13 @@ def dry_rank(a):
     h.close()
 
 
-def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check):
+def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check, C=1, modes=((0, "one_wave_per_channel"), (1, "time_tiled"))):
     """BASELINE configs[1], one channel on one GPU, as one long call per step (2^20 complex samples): the calls the
     time-tiled kernels are for (psk_tile_kernel.h, psk_pfit.h), with the one-wave-per-channel kernels timed beside them
     (PSK_SOFT_OPT_TIME_TILED = 0) and, with --check, the last call compared with the oracle bit for bit."""
     from psk_soft_amd.stimulus import synth_channels_torch
 
-    N, C = 1 << 20, 1
+    N = 1 << 20
     iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED1000, periodic=True)
     bpb = {2: 1, 4: 2, 8: 3}.get(M, 0)
     cap = (N // S + 2 + 63) // 64 * 64
@@ -207,12 +210,13 @@ def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check):
     sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)
     bits = torch.empty((C, max(bpb, 1) * cap), dtype=torch.int16, device=dev)
     pk, out = (pl.Packet * C)(), (pl.Output * C)()
-    pk[0].data, pk[0].n_floats, pk[0].sri_xdelta, pk[0].sri_mode, pk[0].present = iq[0].data_ptr(), 2 * N, 0.01, 1, 1
-    out[0].soft, out[0].bits, out[0].phase, out[0].sampleIndex = soft[0].data_ptr(), bits[0].data_ptr(), phase[0].data_ptr(), sidx[0].data_ptr()
-    out[0].cap_symbols = cap
+    for c in range(C):
+        pk[c].data, pk[c].n_floats, pk[c].sri_xdelta, pk[c].sri_mode, pk[c].present = iq[c].data_ptr(), 2 * N, 0.01, 1, 1
+        out[c].soft, out[c].bits, out[c].phase, out[c].sampleIndex = soft[c].data_ptr(), bits[c].data_ptr(), phase[c].data_ptr(), sidx[c].data_ptr()
+        out[c].cap_symbols = cap
     stream = torch.cuda.Stream(device=dev)
     res, warm, steps = {}, 3, 10
-    for mode, key in ((0, "one_wave_per_channel"), (1, "time_tiled")):
+    for mode, key in modes:
         h = pl.Handle(C, device=dev_index)
         h.set_option(pl.Handle.OPT_TIME_TILED, mode)
         h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=numAvg, phaseAvg=phaseAvg)
@@ -227,12 +231,13 @@ def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check):
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / steps
         st = h.stats()
-        res[key] = {"ms_per_call": ms, "Msamples_per_s": N / ms / 1e3,
+        res[key] = {"ms_per_call": ms, "Msamples_per_s": C * N / ms / 1e3, "frac_of_hbm_read_roofline": 8.0 * C * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernel_stats": {k: st[k] for k in ("channels_tiled", "channels_parallel_fit", "parallel_fit_refusals", "fit_chain_blocks")}}
         h.close()
-    res["workload"] = "%s, samplesPerBaud=%d, 1 channel x %d complex samples per call, numAvg=%d, phaseAvg=%d (BASELINE configs[1])" % (
-        {2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, N, numAvg, phaseAvg)
-    res["speedup"] = res["one_wave_per_channel"]["ms_per_call"] / res["time_tiled"]["ms_per_call"]
+    res["workload"] = "%s, samplesPerBaud=%d, %d channel%s x %d complex samples per call, numAvg=%d, phaseAvg=%d%s" % (
+        {2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, C, "" if C == 1 else "s", N, numAvg, phaseAvg, " (BASELINE configs[1])" if C == 1 else "")
+    if "one_wave_per_channel" in res and "time_tiled" in res:
+        res["speedup"] = res["one_wave_per_channel"]["ms_per_call"] / res["time_tiled"]["ms_per_call"]
     if check:
         import numpy as np
 
@@ -255,17 +260,179 @@ def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check):
     return res
 
 
+def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numAvg=100, phaseAvg=50, mixed=False, phase0=False,
+              steps=20, warmup=30, check=True, seed=0x5EED2000):
+    """One more configuration measured the way the headline is (inputs and outputs resident in HBM, HIP events on the
+    launch stream, state carried across steps), with fewer steps, for the default line's `configs3_per_gpu`, `mixed`
+    and `worst_case` entries; channels 0 and C-1 replayed through the oracle over all calls."""
+    from psk_soft_amd.stimulus import synth_channels_torch
+
+    if mixed:
+        props = [dict(samplesPerBaud=S, constelationSize=(2, 4, 8)[c % 3], phaseAvg=(10, 50, 200)[(c // 3) % 3],
+                      numAvg=(25, 100, 400)[(c // 9) % 3]) for c in range(C)]
+        bpb_max = 3
+    else:
+        props = [dict(samplesPerBaud=S, constelationSize=M, numAvg=numAvg, phaseAvg=phaseAvg)] * C
+        bpb_max = {2: 1, 4: 2, 8: 3}.get(M, 1)
+    h = pl.Handle(C, device=dev_index, max_window_samples=max(16384, S * max(q["numAvg"] for q in props)),
+                  max_phase_avg=max(512, max(q["phaseAvg"] for q in props)))
+    if mixed:
+        h.configure(0, props)
+        iq = torch.empty((C, 2 * N), dtype=torch.float32, device=dev)
+        for j, Mj in enumerate((2, 4, 8)):
+            idx = torch.arange(j, C, 3, device=dev)
+            iq[idx] = synth_channels_torch(idx.numel(), Mj, S, N, dev, seed=seed + j, periodic=True)
+    else:
+        h.configure_all(**props[0])
+        iq = synth_channels_torch(C, M, S, N, dev, seed=seed, periodic=True, phase0=phase0)
+    cap = (N // S + 2 + 63) // 64 * 64
+    soft = torch.empty((C, 2 * cap), dtype=torch.float32, device=dev)
+    phase = torch.empty((C, cap), dtype=torch.float32, device=dev)
+    sidx = torch.empty((C, cap), dtype=torch.int16, device=dev)
+    bits = torch.empty((C, bpb_max * cap), dtype=torch.int16, device=dev)
+    pk, out = (pl.Packet * C)(), (pl.Output * C)()
+    for c in range(C):
+        pk[c].data, pk[c].n_floats, pk[c].sri_xdelta, pk[c].sri_mode, pk[c].present = iq[c].data_ptr(), 2 * N, 0.01, 1, 1
+        out[c].soft, out[c].bits, out[c].phase, out[c].sampleIndex = soft[c].data_ptr(), bits[c].data_ptr(), phase[c].data_ptr(), sidx[c].data_ptr()
+        out[c].cap_symbols = cap
+    stream = torch.cuda.Stream(device=dev)
+    for _ in range(warmup):
+        h.process_device(0, pk, out, stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        h.process_device(0, pk, out, stream=stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    st = h.stats()
+    n_out = int(out[0].n_symbols)
+    res = {"workload": name, "channels": C, "samples_per_channel_per_step": N, "ms_per_step": ms,
+           "Msamples_per_s": C * N / ms / 1e3, "frac_of_hbm_read_roofline": 8.0 * C * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "steps": steps, "warmup": warmup,
+           "kernel_stats": {k: st[k] for k in ("channels_fast", "channels_exact_timing", "channels_sequential", "unwrap_blocks",
+                                               "unwrap_extra_passes", "timing_exact_blocks", "fit_chain_blocks")}}
+    if check:
+        import numpy as np
+
+        from oracle import pyoracle as po
+
+        same = True
+        for c in (0, C - 1):
+            comp = po.OracleComponent()
+            for kk, vv in props[c].items():
+                setattr(comp, kk, vv)
+            x = iq[c].cpu().numpy()
+            r = None
+            for _ in range(warmup + steps):
+                r = comp.service(x, 0.01, sriChanged=False)
+            b = {2: 1, 4: 2, 8: 3}.get(props[c]["constelationSize"], 0)
+            for g, w, dt in ((soft[c, : 2 * n_out], r.soft, np.uint32), (phase[c, :n_out], r.phase, np.uint32),
+                             (bits[c, : b * n_out], r.bits, np.int16), (sidx[c, :n_out], r.index, np.int16)):
+                ft = np.float32 if dt is np.uint32 else np.int16
+                same = same and np.array_equal(g.cpu().numpy().view(dt), np.ascontiguousarray(w, ft).view(dt))
+        res["check"] = {"channels": [0, C - 1], "calls_replayed": warmup + steps, "all_four_streams_bit_identical": bool(same)}
+        assert same, "%s: the HIP path differs from the oracle" % name
+    h.close()
+    del iq, soft, phase, sidx, bits
+    torch.cuda.empty_cache()
+    return res
+
+
+def end_to_end(pl, torch, dev, dev_index, C=4096, N=32768, M=4, S=8, calls=3):
+    """"end-to-end incl. H2D/D2H separately" -- the same call with packets and results in HOST memory:
+    psk_soft_process_host (pageable buffers, staged through pinned memory in chunks, three chunks in flight) and the
+    zero-copy form (page-locked buffers from psk_soft_host_alloc handed to psk_soft_process_device: the kernels read and
+    write them over PCIe).  Never `value`: these rates are the link's and the host's, not the kernel's."""
+    import numpy as np
+
+    from psk_soft_amd.stimulus import synth_channels_torch
+
+    iq = synth_channels_torch(C, M, S, N, dev, seed=0x5EED3000, periodic=True).cpu().numpy()
+    res = {"workload": "QPSK, samplesPerBaud=%d, %d channels x %d complex samples per call, packets and results in host memory" % (S, C, N)}
+    h = pl.Handle(C, device=dev_index)
+    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=50)
+    pkts = [dict(data=iq[c], xdelta=0.01) for c in range(C)]
+    h.process_host(0, pkts)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        h.process_host(0, pkts)
+    dt = (time.perf_counter() - t0) / calls
+    h.close()
+    in_b = 8.0 * C * N
+    out_b = C * (N // S) * (8 + 4 + 2 + 4)
+    res["process_host"] = {"ms_per_call": dt * 1e3, "Msamples_per_s": C * N / dt / 1e6, "pcie_in_GBps": in_b / dt / 1e9,
+                           "pcie_out_GBps": out_b / dt / 1e9, "note": "pageable numpy buffers; includes the ctypes / numpy marshalling of this harness"}
+    # zero copy: page-locked packets and result rows, device-pointer entry point
+    cap = (N // S + 2 + 63) // 64 * 64
+    h = pl.Handle(C, device=dev_index)
+    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=50)
+    hin = pl.host_alloc(C * 2 * N, np.float32)
+    hsoft, hphase = pl.host_alloc(C * 2 * cap, np.float32), pl.host_alloc(C * cap, np.float32)
+    hbits, hsidx = pl.host_alloc(C * 2 * cap, np.int16), pl.host_alloc(C * cap, np.int16)
+    hin.reshape(C, 2 * N)[:] = iq
+    pk, out = (pl.Packet * C)(), (pl.Output * C)()
+    for c in range(C):
+        pk[c].data, pk[c].n_floats, pk[c].sri_xdelta, pk[c].sri_mode, pk[c].present = hin.ctypes.data + 8 * N * c, 2 * N, 0.01, 1, 1
+        out[c].soft, out[c].phase = hsoft.ctypes.data + 8 * cap * c, hphase.ctypes.data + 4 * cap * c
+        out[c].bits, out[c].sampleIndex = hbits.ctypes.data + 4 * cap * c, hsidx.ctypes.data + 2 * cap * c
+        out[c].cap_symbols = cap
+    h.process_device(0, pk, out)
+    h.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        h.process_device(0, pk, out)
+    h.synchronize()
+    dt = (time.perf_counter() - t0) / calls
+    res["zero_copy"] = {"ms_per_call": dt * 1e3, "Msamples_per_s": C * N / dt / 1e6, "pcie_in_GBps": in_b / dt / 1e9,
+                        "pcie_out_GBps": out_b / dt / 1e9, "note": "page-locked buffers (psk_soft_host_alloc) read and written by the kernels over PCIe"}
+    h.close()
+    for a in (hin, hsoft, hphase, hbits, hsidx):
+        pl.host_free(a)
+    return res
+
+
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def count_gpus_without_hip():
+    """GPUs this process could use, WITHOUT initialising HIP in it (the launcher's children each open their own device; a
+    parent that had opened the GPU and then forked would hand them a runtime in an undefined state).  The kernel driver's
+    topology lists every agent; GPU nodes are those with SIMDs.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict."""
+    import glob
+
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            kv = dict(l.split(None, 1) for l in open(prop).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(kv.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""])) if n else len([x for x in v.split(",") if x.strip() != ""])
+    return n
+
+
 def launch_ranks(a):
-    """--gpus N > 1 without a launcher: start N ranks of this script, one per GPU (never after this process has
-    touched a GPU: a child inherits nothing but the environment)."""
+    """--gpus N > 1 without a launcher: start N ranks of this script, one per GPU.  This process never touches a GPU (it
+    does not even import torch); it polls its children, and the first one that fails takes the others down with it."""
     import socket
     import subprocess
 
     n = a.gpus
     if os.environ.get("PSK_BENCH_DRY") != "1":
-        import torch  # (device_count() does not initialise the GPU)
-
-        visible = torch.cuda.device_count()
+        visible = count_gpus_without_hip()
         if n > visible and os.environ.get("PSK_BENCH_SHARE_GPU") != "1":  # (rehearsal: several gloo ranks on one GPU)
             raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (n, visible))
     sock = socket.socket()
@@ -278,21 +445,44 @@ def launch_ranks(a):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # rank 0's stdout is read by a thread (a full pipe must not block it); the ranks are polled: the first failure, or the
+    # overall limit, ends the others -- a rank stuck in a barrier behind a dead peer would otherwise wait out the backend's timeout
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("PSK_BENCH_LAUNCH_TIMEOUT", "1500"))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0] if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    text = (out0[0] if out0 else b"").decode()
     # rank 0's JSON line and nothing else on stdout (what libraries print there -- gloo announces its peers -- goes to stderr)
-    line = [l for l in out0.splitlines() if l.startswith("{")]
-    for l in out0.splitlines():
+    line = [l for l in text.splitlines() if l.startswith("{")]
+    for l in text.splitlines():
         if not line or l is not line[-1]:
             print(l, file=sys.stderr)
     if line:
         sys.stdout.write(line[-1] + "\n")
     sys.stdout.flush()
     if rc:
-        raise SystemExit("bench.py: a rank failed (exit status %d)" % rc)
+        raise SystemExit("bench.py: a rank failed or the launch timed out (exit status %d)" % rc)
     if not line or json.loads(line[-1]).get("n_gpus") != n:
         raise SystemExit("bench.py: rank 0 did not report %d ranks" % n)
 
@@ -479,7 +669,8 @@ def main():
                          "per-channel phaseAvg {10,50,200} and numAvg {25,100,400}, inputs/outputs resident in HBM" % (S, C, N))
             if a.mixed else
             "%s, samplesPerBaud=%d, %d channels per GPU x %d complex samples per step, numAvg=%d, phaseAvg=%d, "
-            "inputs/outputs resident in HBM" % ({2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, C, N, a.numAvg, a.phaseAvg),
+            "inputs/outputs resident in HBM%s" % ({2: "BPSK", 4: "QPSK", 8: "8-PSK"}.get(M, "M=%d" % M), S, C, N, a.numAvg, a.phaseAvg,
+                                                 ", every channel at zero constellation phase and zero carrier offset" if a.phase0 else ""),
             "channels_per_gpu": C,
             "samples_per_channel_per_step": N,
             "symbols_out_per_channel_per_step": n_out,
@@ -510,6 +701,7 @@ def main():
         iq_host = iq[:n_host].cpu().numpy()
         res["cpu_baseline"] = cpu_baseline(iq_host, M, S, a.numAvg, a.phaseAvg, a.cpu_seconds)
         res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        res["cpu_baseline"]["cpu_model"] = cpu_model()
 
     if a.check and rank == 0:
         from oracle import pyoracle as po
@@ -540,12 +732,34 @@ def main():
     if rank == 0 and world == 1 and not a.mixed and not a.no_few:
         res["few_channels"] = few_channels(pl, torch, dev, dev_index, M, S, a.numAvg, a.phaseAvg, a.check)
 
+    if rank == 0 and world == 1 and headline and not a.phase0 and not a.no_extra:
+        # the other BASELINE configurations and the two ends of SURVEY section 8(d), measured beside the headline in the same run
+        h.close()
+        del iq, soft, phase, sidx, bits
+        torch.cuda.empty_cache()
+        res["configs3_per_gpu"] = sub_bench(pl, torch, dev, dev_index, "8-PSK, samplesPerBaud=10, 4096 channels x 262144 complex samples per step "
+                                            "(BASELINE configs[3]: one GPU's shard of the 32768 channels)", M=8, S=10, check=a.check)
+        res["mixed"] = sub_bench(pl, torch, dev, dev_index, "mixed BPSK/QPSK/8-PSK, samplesPerBaud=8, 4096 channels x 262144 complex samples per step, "
+                                 "per-channel phaseAvg {10,50,200} and numAvg {25,100,400} (BASELINE configs[4])", mixed=True, check=a.check)
+        wc = sub_bench(pl, torch, dev, dev_index, "QPSK, samplesPerBaud=8, 4096 channels x 262144 complex samples per step, EVERY channel at zero "
+                       "constellation phase and zero carrier offset (the signal shape of the reference's own test): LinearFit's sums hover "
+                       "around zero in every channel, every block takes the reference-order chain", phase0=True, check=a.check)
+        wc["slowdown_vs_headline"] = wc["ms_per_step"] / dev_ms_avg
+        res["worst_case"] = wc
+        if not a.no_few:
+            for cf in (64, 512):
+                res["few_channels_%d" % cf] = few_channels(pl, torch, dev, dev_index, M, S, a.numAvg, a.phaseAvg, a.check, C=cf,
+                                                           modes=((1, "time_tiled"),))
+        res["end_to_end"] = end_to_end(pl, torch, dev, dev_index)
+        h = None
+
     if rank == 0:
         print(json.dumps(res))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    h.close()
+    if h is not None:
+        h.close()
 
 
 if __name__ == "__main__":

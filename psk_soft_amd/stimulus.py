@@ -1,58 +1,16 @@
 """Synthetic PSK stimuli.
 
-Two generators:
-
-* ``gen_psk`` restates the stimulus of the reference's own component test
-  (reference tests/test_psk_soft.py:98-117): ideal constellation points, a
-  rectangular pulse and 1e-4 uniform noise on the real part only, driven by
-  Python's Mersenne Twister seeded with 100 (``random.seed(100)``,
-  tests/test_psk_soft.py:41).  The reference test is Python 2; its
-  ``random.choice(seq)`` is ``seq[int(random() * len(seq))]`` there, which is
-  what ``_py2_choice`` does so that the symbol stream is the one Python 2 draws.
-
-* ``synth_channels`` is the benchmark / parity workload of SURVEY.md section 8(d):
-  per-channel counter-based PRNG (Philox keyed by 0x5EED0000 + channel), random
-  M-PSK symbols with a per-channel phase offset, an asymmetric single-peaked
-  pulse, per-channel gain, a small carrier offset and AWGN.
+``synth_channels`` is the benchmark / parity workload of SURVEY.md section 8(d):
+per-channel counter-based PRNG (Philox keyed by 0x5EED0000 + channel), random
+M-PSK symbols with a per-channel phase offset, an asymmetric single-peaked
+pulse, per-channel gain, a small carrier offset and AWGN.
+(The stimulus of the reference's own component test lives with the tests: tests/ref_stimulus.py.)
 """
 import math
-import random as _random
 
 import numpy as np
 
 SEED_BASE = 0x5EED0000
-
-
-def _py2_choice(rng, seq):
-    return seq[int(rng.random() * len(seq))]
-
-
-def gen_psk(num_symbols, samp_per_baud=8, num_syms=4, differential=False, rng=None):
-    """Return (interleaved float32 I/Q, list of transmitted complex symbols)."""
-    if rng is None:
-        rng = _random.Random(100)
-    syms = list(range(num_syms))
-    phase = [2 * math.pi * x / num_syms for x in syms]
-    cx = [complex(math.cos(x), math.sin(x)) for x in phase]
-    out = np.empty(2 * num_symbols * samp_per_baud, dtype=np.float64)
-    input_symbols = []
-    last = 1
-    pos = 0
-    for _ in range(num_symbols):
-        x = _py2_choice(rng, syms)
-        x_cx = cx[x]
-        input_symbols.append(x_cx)
-        if differential:
-            val = x_cx * last
-            last = val
-        else:
-            val = x_cx
-        for _ in range(samp_per_baud):
-            v = val + 0.0001 * rng.random()
-            out[pos] = v.real
-            out[pos + 1] = v.imag
-            pos += 2
-    return out.astype(np.float32), input_symbols
 
 
 def pulse_shape(S):
@@ -62,13 +20,16 @@ def pulse_shape(S):
     return 0.2 + 0.8 * np.sin(np.pi * (j + 0.9) / (S + 1.3))
 
 
-def synth_channel(channel, M, S, n_complex, sigma=0.01, cfo_max=1e-3, dtype=np.float32, cfo=None):
+def synth_channel(channel, M, S, n_complex, sigma=0.01, cfo_max=1e-3, dtype=np.float32, cfo=None, phi0=None):
     """One channel of the section-8(d) workload as interleaved I/Q (length 2*n_complex).
-    cfo: M * (carrier phase advance per symbol) given outright instead of drawn from [-cfo_max, cfo_max]."""
+    cfo: M * (carrier phase advance per symbol) given outright instead of drawn from [-cfo_max, cfo_max];
+    phi0: the constellation's phase offset given outright (phi0 = 0, cfo = 0: the signal shape of the reference's own test,
+    reference tests/test_psk_soft.py:98-117, LinearFit's sums hovering around zero)."""
     g = np.random.Generator(np.random.Philox(key=SEED_BASE + int(channel)))
     n_sym = -(-n_complex // S)
     k = g.integers(0, M, size=n_sym)
-    phi0 = g.uniform(0.0, 2 * np.pi / M)
+    phi0_drawn = g.uniform(0.0, 2 * np.pi / M)
+    phi0 = phi0_drawn if phi0 is None else float(phi0)
     gain = g.uniform(0.5, 2.0)
     dphi = g.uniform(-cfo_max, cfo_max) / M  # M * dphi per symbol in [-cfo_max, cfo_max]
     if cfo is not None:

@@ -193,7 +193,7 @@ def test_tie_heavy_signal_takes_the_exact_timing_path(oracle_mod):
     the first-maximum tie rule has to match the reference."""
     import random as _random
 
-    from psk_soft_amd.stimulus import gen_psk
+    from ref_stimulus import gen_psk
 
     data, _ = gen_psk(3000, samp_per_baud=8, num_syms=4, differential=False, rng=_random.Random(11))
     for numAvg, in_kernel in ((100, True), (200, False)):
@@ -232,7 +232,8 @@ def test_host_sized_energy_ring(oracle_mod):
     anywhere."""
     import random as _random
 
-    from psk_soft_amd.stimulus import gen_psk, synth_channel
+    from psk_soft_amd.stimulus import synth_channel
+    from ref_stimulus import gen_psk
 
     rng = random.Random(77)
     for A_set, n_set in (((1, 2, 3, 28), (1, 10, 50)), ((76, 100, 5), (50, 128, 129)), ((127, 128, 64, 2), (384, 200, 1))):
@@ -284,7 +285,8 @@ def test_every_samples_per_baud_2_to_16_on_the_wave_scan_kernel(oracle_mod):
     through the time-tiled kernels' run-time front stage (round 1: the reference-order kernel)."""
     import random as _random
 
-    from psk_soft_amd.stimulus import gen_psk, synth_channel
+    from psk_soft_amd.stimulus import synth_channel
+    from ref_stimulus import gen_psk
 
     rng = random.Random(31)
     props, iqs, cuts = [], [], []
@@ -1039,7 +1041,7 @@ def test_large_phase_estimate_is_bit_identical(oracle_mod, S, M, n):
     assert peak > 700.0, peak  # the regime this test is about was reached
 
 
-def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels, expect_tiled=None):
+def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels, expect_tiled=None, phase0=False, min_chain_blocks=0):
     """C channels through psk_soft_process_device (device-resident packets and output rows, rows on 128-byte
     boundaries as bench.py lays them out), `calls` = list of samples per call; the channels in check_channels are
     replayed through the oracle and compared bit for bit on all four streams."""
@@ -1050,7 +1052,8 @@ def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels, expect_ti
 
     total = sum(calls)
     with ThreadPoolExecutor(8) as ex:
-        host = np.stack(list(ex.map(lambda c: synth_channel(70000 + 13 * M + S + c, M, S, total), range(C))))
+        kw = dict(cfo=0.0, phi0=0.0) if phase0 else {}
+        host = np.stack(list(ex.map(lambda c: synth_channel(70000 + 13 * M + S + c, M, S, total, **kw), range(C))))
     bpb = {2: 1, 4: 2, 8: 3}[M]
     cap = (max(calls) // S + 2 + 63) // 64 * 64
     h = pl.Handle(C, device=0)
@@ -1084,6 +1087,8 @@ def _device_batch(oracle_mod, M, S, A, n_ph, C, calls, check_channels, expect_ti
             h.synchronize()
             st = h.stats()
             assert st["channels_fast"] == C and st["channels_sequential"] == 0, st
+            if k > 0:
+                assert st["fit_chain_blocks"] >= min_chain_blocks, st
             if expect_tiled is not None:
                 assert st["channels_tiled"] == expect_tiled, st
             soft = h.download(d_soft, (C, 2 * cap), np.float32)
@@ -1128,6 +1133,17 @@ def test_machine_filling_batch_8psk_s10(oracle_mod):
     not a multiple of 10 samples (the symbol clock carries the leftovers from call to call)."""
     C = 4096
     _device_batch(oracle_mod, 8, 10, 100, 50, C, [8197, 8191], sorted(set(range(0, C, 32)) | {C - 1}))
+
+
+def test_machine_filling_batch_all_channels_at_zero_phase(oracle_mod):
+    """The data-dependent worst case of the wave-scan kernel, at the bench's residency: 4096 channels whose constellation sits
+    at zero phase with no carrier offset -- the signal shape of the reference's own component test (reference
+    tests/test_psk_soft.py:98-117).  The M-th-power phase is noise around zero, LinearFit's running sums hover around zero and
+    cross binades from symbol to symbol: the wave-parallel candidates of the sums rarely verify and most blocks take the
+    reference-order recurrence (fit_chain_blocks), in EVERY wave of the launch.  Bit for bit against the oracle."""
+    C = 4096
+    _device_batch(oracle_mod, 4, 8, 100, 50, C, [8192, 8192], sorted(set(range(0, C, 64)) | {C - 1}), phase0=True,
+                  min_chain_blocks=C * 2)
 
 
 def test_round1_one_ulp_case_is_bit_identical_now(oracle_mod):

@@ -23,7 +23,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from psk_soft_amd.stimulus import gen_psk
+from ref_stimulus import gen_psk
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
