@@ -302,15 +302,17 @@ PSK_DEV float fit_value_known(double ySum, double xySum, const FitKnown &k, floa
 PSK_DEV void qpsk_bits(float re, float im, bool sign_map, int &b0, int &b1)
 {
     int r, m;
-    if (sign_map) {  // (wave-uniform: a scalar branch, one of the two pairs of compares is executed)
+    if (sign_map) {  // (wave-uniform: a scalar branch, one of the two pairs is executed)
         r = re > 0.0f;
         m = im > 0.0f;
     } else {
-        r = re != 0.0f;
-        m = im != 0.0f;
+        // "!= 0" (true for a NaN) on the bits: magnitude + 0x7fffffff carries into the sign bit unless the magnitude is zero
+        // (integer additions and shifts instead of compares and selects: a third of their cost on gfx950)
+        r = -((int)lm_opaque((__float_as_uint(re) & 0x7fffffffu) + 0x7fffffffu) >> 31);
+        m = -((int)lm_opaque((__float_as_uint(im) & 0x7fffffffu) + 0x7fffffffu) >> 31);
     }
     b0 = r ^ m;
-    b1 = !m;
+    b1 = m ^ 1;
 }
 
 // abs(phaseEstimate) > wrapValue with ::abs(int) (quirk Q5, cpp/psk_soft.cpp:596)

@@ -54,6 +54,15 @@ __device__ __forceinline__ double lm_kd(int dep)
 #endif
 
 PSK_HD uint32_t lm_asuint(float f) { return __builtin_bit_cast(uint32_t, f); }
+// the value, opaque to the optimiser on the device: keeps integer arithmetic on bit patterns from being folded back into the
+// compares and selects it was written to replace (no instruction is emitted)
+PSK_HD uint32_t lm_opaque(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 PSK_HD float lm_asfloat(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 // ---------------------------------------------------------------------------------
@@ -306,7 +315,10 @@ PSK_HD float lm_atan2f_ordinary_t(float y, float x, bool *special, const Tab &ta
     const uint32_t ia = lm_asuint(a);
     // atanf(a), a >= 0.  The first range also serves a < 2^-29, where s_atanf.c returns its
     // argument: t - t*(s1+s2) rounds to t there.
-    const int id = (int)(ia >= 0x3ee00000u) + (int)(ia >= 0x3f300000u) + (int)(ia >= 0x3f980000u) + (int)(ia >= 0x401c0000u);
+    // (the range index by subtractions and sign bits -- ia and the bounds are below 2^31 -- instead of four compares and the
+    // selects behind them: compares and selects cost gfx950 1.6 to 4 times a subtraction, tools/micro/valu_rate_probe.hip)
+    const int id = -(((int)lm_opaque(0x3edfffffu - ia) >> 31) + ((int)lm_opaque(0x3f2fffffu - ia) >> 31) +
+                     ((int)lm_opaque(0x3f97ffffu - ia) >> 31) + ((int)lm_opaque(0x401bffffu - ia) >> 31));
     const float c1a = tab.get(0, id) * a, d1a = tab.get(2, id) * a;
     const float num = c1a + tab.get(1, id);
     const float den = d1a + tab.get(3, id);
@@ -414,22 +426,24 @@ PSK_HD void lm_sincosf_ordinary(float y, float *sp, float *cp, bool *special, in
             q = n + sign;
         }
     }
-    const double sgn = ((q + 1) & 2) ? -1.0 : 1.0;  // sign[q & 3] = {1,-1,-1,1}
-    const double sg = (q & 2) ? -1.0 : 1.0;         // second table entry: cosine coefficients negated
-    const double xs = xr * sgn, x2 = xr * xr;
+    // sign[q & 3] = {1,-1,-1,1} on the sine's argument, and the second table entry (cosine coefficients negated) for q & 2:
+    // both polynomials are evaluated for the positive signs and the sign put on the result -- every operation in them is
+    // odd (sine) resp. linear (cosine) in the sign and rounding to nearest is symmetric, so the bits are the same; it saves
+    // a multiplication and six selects per symbol
+    const double x2 = xr * xr;
     // sine polynomial
-    const double x3 = xs * x2;
+    const double x3 = xr * x2;
     const double s1 = __builtin_fma(x2, S3, S2);
     const double x7 = x3 * x2;
-    const double s = __builtin_fma(x3, S1, xs);
-    const float ps = (float)__builtin_fma(x7, s1, s);
+    const double s = __builtin_fma(x3, S1, xr);
+    const float ps = lm_asfloat(lm_asuint((float)__builtin_fma(x7, s1, s)) ^ (((uint32_t)(q + 1) & 2u) << 30));
     // cosine polynomial
     const double x4 = x2 * x2;
-    const double c2 = __builtin_fma(x2, sg * C4, sg * C3);
-    const double c1 = __builtin_fma(x2, sg * C1, sg * C0);
+    const double c2 = __builtin_fma(x2, C4, C3);
+    const double c1 = __builtin_fma(x2, C1, C0);
     const double x6 = x4 * x2;
-    const double c = __builtin_fma(x4, sg * C2, c1);
-    const float pc = (float)__builtin_fma(x6, c2, c);
+    const double c = __builtin_fma(x4, C2, c1);
+    const float pc = lm_asfloat(lm_asuint((float)__builtin_fma(x6, c2, c)) ^ (((uint32_t)q & 2u) << 30));
     const bool odd = (n & 1) != 0;
     const bool tiny = top < lm_abstop12(0x1p-12f);
     const bool nonfinite = top >= lm_abstop12(__builtin_inff());
