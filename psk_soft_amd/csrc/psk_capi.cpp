@@ -462,8 +462,11 @@ uint64_t psk_soft_output_capacity(const psk_soft_handle_t *h, uint32_t ch, uint6
     return (n_complex + S - 1) / S + 1;
 }
 
-psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch,
-                                        const psk_soft_packet_t *pkts, psk_soft_output_t *outs, void *stream_v)
+// One pass of the control plane over a batch and the launches it asks for.  cont[i], pieces of a call the library
+// has cut (process_device below): bit 0 = packet i continues the call of the packet before it (plan_call's `cont`), bit 1 = more
+// pieces of the call follow (no end-of-call wrap yet).
+static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, const psk_soft_packet_t *pkts,
+                                     psk_soft_output_t *outs, void *stream_v, const uint8_t *cont)
 {
     if (!h || !pkts || !outs || !nch || (uint64_t)ch0 + nch > h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process: bad arguments");
@@ -498,7 +501,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 return;
             }
             psk::ChanPlan &p = plans[i];
-            psk_soft_status st = psk::plan_call(next[i], lim, pkts[i], outs[i], p);
+            psk_soft_status st = psk::plan_call(next[i], lim, pkts[i], outs[i], p, cont && (cont[i] & 1u));
             if (st != PSK_SOFT_OK) {
                 r.st = st, r.bad = i, r.why = 0;
                 return;
@@ -511,6 +514,8 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 return;
             }
             p.lf_flags |= extra_flags;
+            if (cont && (cont[i] & 2u))
+                p.lf_flags |= psk::PLAN_NO_WRAP;  // (more pieces of this call follow)
             r.any = true;
             if (p.mode == psk::PLAN_FAST) {
                 if (p.n_out && (p.lf_flags & psk::PLAN_ANYFRONT)) {
@@ -861,6 +866,131 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     h->slot_stream[slot] = stream;
     h->slot_ch0[slot] = ch0;
     h->slot_nch[slot] = nch;
+    return PSK_SOFT_OK;
+}
+
+// The public entry.  A call that would emit more than 2^20 symbols in one channel, or run LinearFit::count past 2^20 in the
+// middle (the reference then rebuilds the fit's sums at that symbol, cpp/psk_soft.cpp:51-52, and its energy sums after it,
+// :582-583), is cut at those boundaries inside the library: the pieces are planned as continuations of ONE serviceFunction() call
+// (no prologue between them) and run on the wave-scan / time-tiled kernels like any other call -- round 2 handed such calls to the
+// reference-order kernel, 4.7 us per symbol on one lane.  Everything else goes straight through.
+psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch,
+                                        const psk_soft_packet_t *pkts, psk_soft_output_t *outs, void *stream_v)
+{
+    if (!h || !pkts || !outs || !nch || (uint64_t)ch0 + nch > h->nch)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process: bad arguments");
+    // symbols a packet of n samples can emit at most, and how many the kernels take in one piece
+    auto piece_symbols = [&](uint32_t i) -> uint64_t {
+        const psk::ChanCtl &c = h->ctl[ch0 + i];
+        const uint64_t used = (c.lf_recompute_pending || c.lf_count >= psk::kResyncCount) ? 0 : c.lf_count;
+        return psk::kResyncCount - used;
+    };
+    bool any_long = false;
+    if (!h->lim.force_seq)
+        for (uint32_t i = 0; i < nch && !any_long; i++) {
+            if (!pkts[i].present || pkts[i].sri_mode != 1)
+                continue;
+            const uint64_t S = h->ctl[ch0 + i].props.samplesPerBaud ? h->ctl[ch0 + i].props.samplesPerBaud : 1;
+            // (a call resets LinearFit::count at its top whenever the SRI block runs, quirk Q2: only the packet length matters then;
+            // the count carried in is the conservative bound)
+            any_long = (pkts[i].n_floats / 2) / S + h->ctl[ch0 + i].props.numAvg + 2 > piece_symbols(i) ||
+                       (pkts[i].n_floats / 2) / S + 2 > psk::kResyncCount;
+        }
+    if (!any_long)
+        return process_round(h, ch0, nch, pkts, outs, stream_v, nullptr);
+
+    // ---- pieces ----
+    std::vector<psk_soft_packet_t> pk(pkts, pkts + nch);
+    std::vector<psk_soft_output_t> ou(outs, outs + nch), total(outs, outs + nch);
+    std::vector<uint64_t> left(nch);   // floats of the packet not yet handed over
+    std::vector<uint8_t> cont(nch, 0);
+    std::vector<uint32_t> mode_of(nch, psk::PLAN_SKIP);  // (statistics: the kernel of each channel's last piece)
+    for (uint32_t i = 0; i < nch; i++) left[i] = pkts[i].present ? pkts[i].n_floats : 0;
+    for (int round = 0;; round++) {
+        bool more = false;
+        for (uint32_t i = 0; i < nch; i++) {
+            psk_soft_packet_t &q = pk[i];
+            if (round > 0) {
+                q.present = left[i] ? 1 : 0;  // (a channel whose packet is used up sits the later rounds out)
+                q.sriChanged = 0;
+                q.inputQueueFlushed = 0;
+            }
+            cont[i] = round > 0 ? 1 : 0;
+            if (!q.present || q.sri_mode != 1) {
+                left[i] = 0;
+                continue;
+            }
+            const psk::ChanCtl &c = h->ctl[ch0 + i];
+            const uint64_t S = c.props.samplesPerBaud ? c.props.samplesPerBaud : 1, A = c.props.numAvg;
+            // the first round runs the call's prologue, which (quirk Q2) resets LinearFit::count in practically every call: plan on a
+            // copy to learn what this piece would emit, and shorten it to an even number of symbols within the limit (the output
+            // rows of the next piece must stay 4-byte aligned: bits and sampleIndex are 2 bytes a symbol)
+            uint64_t n_fl = left[i];
+            for (int attempt = 0; attempt < 4; attempt++) {
+                psk::ChanCtl probe = c;
+                psk::ChanPlan pl;
+                psk_soft_packet_t qq = q;
+                qq.n_floats = n_fl;
+                psk_soft_output_t oo = ou[i];
+                oo.cap_symbols = ~0ull;
+                if (psk::plan_call(probe, h->lim, qq, oo, pl, (cont[i] & 1u) != 0) != PSK_SOFT_OK)
+                    break;  // (the real pass reports it)
+                const uint64_t lim_sym = psk::kResyncCount - pl.lf_count0 < psk::kResyncCount ? psk::kResyncCount - pl.lf_count0 : psk::kResyncCount;
+                const bool last = n_fl == left[i];
+                if (oo.n_symbols <= lim_sym && (last || (oo.n_symbols & 1ull) == 0))
+                    break;
+                // too many (or an odd number of) symbols: give the piece fewer samples
+                uint64_t want = oo.n_symbols > lim_sym ? lim_sym : oo.n_symbols - 1;
+                want &= ~1ull;
+                const uint64_t excess = oo.n_symbols - want;
+                const uint64_t cut = 2ull * S * excess;
+                n_fl = n_fl > cut ? n_fl - cut : 2ull * S * (A + 2);
+                (void)A;
+            }
+            q.n_floats = n_fl;
+            left[i] -= n_fl < left[i] ? n_fl : left[i];
+            if (left[i])
+                cont[i] |= 2u;
+            more = more || left[i] != 0;
+        }
+        const psk_soft_status st = process_round(h, ch0, nch, pk.data(), ou.data(), stream_v, cont.data());
+        if (st != PSK_SOFT_OK) {
+            if (round > 0)
+                h->poisoned = true;  // (pieces of the call have run: the channels are in the middle of it)
+            return st;
+        }
+        for (uint32_t i = 0; i < nch; i++) {
+            const psk_soft_output_t &o = ou[i];
+            psk_soft_output_t &t = total[i];
+            if (round == 0) {
+                t = o;
+                t.soft = outs[i].soft, t.bits = outs[i].bits, t.phase = outs[i].phase, t.sampleIndex = outs[i].sampleIndex;
+                t.cap_symbols = outs[i].cap_symbols;
+            } else if (pk[i].present) {
+                t.n_symbols += o.n_symbols;
+                t.n_bits += o.n_bits;
+                t.n_sampleIndex += o.n_sampleIndex;
+                t.n_warn += o.n_warn;
+            }
+            // the next piece reads and writes behind this one
+            if (pk[i].present) {
+                mode_of[i] = h->last_mode[ch0 + i];
+                pk[i].data = pk[i].data ? pk[i].data + pk[i].n_floats : nullptr;
+                pk[i].n_floats = left[i];
+                if (ou[i].soft) ou[i].soft += 2 * o.n_symbols;
+                if (ou[i].bits) ou[i].bits += o.n_bits;
+                if (ou[i].phase) ou[i].phase += o.n_symbols;
+                if (ou[i].sampleIndex) ou[i].sampleIndex += o.n_sampleIndex;
+                ou[i].cap_symbols = ou[i].cap_symbols > o.n_symbols ? ou[i].cap_symbols - o.n_symbols : 0;
+            }
+        }
+        if (!more)
+            break;
+    }
+    for (uint32_t i = 0; i < nch; i++) {
+        outs[i] = total[i];
+        h->last_mode[ch0 + i] = mode_of[i];
+    }
     return PSK_SOFT_OK;
 }
 

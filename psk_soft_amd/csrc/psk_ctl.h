@@ -122,8 +122,11 @@ inline void ctl_linfit_reset(ChanCtl &c, uint32_t fit_cap, const uint64_t *numPt
 // (it plans on a copy), so a refused call leaves the channel untouched.
 inline uint64_t plan_lf_count0(const ChanCtl &c) { return c.lf_recompute_pending ? 0 : c.lf_count; }
 
+// cont = true: the packet CONTINUES the serviceFunction() call of the packet before it -- the library cuts a call that emits
+// more than 2^20 symbols (or that runs LinearFit::count past 2^20) at those boundaries and plans the pieces one after the other
+// (psk_capi.cpp) -- so nothing of the call's prologue (cpp/psk_soft.cpp:353-426) runs again.
 inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_packet_t &pkt,
-                                 psk_soft_output_t &out, ChanPlan &plan)
+                                 psk_soft_output_t &out, ChanPlan &plan, bool cont = false)
 {
     plan = ChanPlan();
     plan.mode = PLAN_SKIP;
@@ -136,7 +139,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         out.ret = PSK_SOFT_NOOP;
         return PSK_SOFT_OK;
     }
-    if (pkt.inputQueueFlushed) {  // :353-357
+    if (pkt.inputQueueFlushed && !cont) {  // :353-357
         out.n_warn++;
         c.props.resetState = 1;
     }
@@ -148,7 +151,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         return PSK_SOFT_ERR_UNSUPPORTED;
     if ((uint64_t)c.props.samplesPerBaud * c.props.numAvg > lim.ring_cap || c.props.phaseAvg > lim.fit_cap)
         return PSK_SOFT_ERR_LIMIT;
-    if (c.props.resetState) {  // :365-372
+    if (c.props.resetState && !cont) {  // :365-372
         c.resetSamplesPerBaud = true;
         c.resetNumSymbols = true;
         c.resetPhaseAvg = true;
@@ -158,7 +161,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
     const uint64_t S = c.props.samplesPerBaud;
     const uint64_t D = S * (uint64_t)c.props.numAvg;
     const uint64_t M = c.props.constelationSize;
-    if (D > c.ring_len)
+    if (D > c.ring_len && !cont)
         c.resetSamplesPerBaud = true;
     uint64_t bpb = 0;
     if (M == 2) bpb = 1;
@@ -166,7 +169,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
     else if (M == 8) bpb = 3;
 
     // :393-405
-    if (pkt.sriChanged || c.resetNumSymbols || c.resetSamplesPerBaud) {
+    if (!cont && (pkt.sriChanged || c.resetNumSymbols || c.resetSamplesPerBaud)) {
         double xdelta = pkt.sri_xdelta;
         if (xdelta != (double)c.sampleRate) {
             c.sampleRate = (float)(1.0 / xdelta);
@@ -179,7 +182,9 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         out.sri_bits_xdelta = xdelta;
     }
     bool resynced = false;
-    if (c.resetSamplesPerBaud) {  // :408-412 -> resyncEnergy :619-636
+    if (cont) {
+        // (a continuation runs none of the three reset blocks: the flags were consumed by the call's first piece)
+    } else if (c.resetSamplesPerBaud) {  // :408-412 -> resyncEnergy :619-636
         c.symEnergySize = S;
         if (c.ring_len > D)
             c.ring_len = D;
@@ -188,11 +193,11 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         c.resetSamplesPerBaud = false;
         resynced = true;
     }
-    if (c.resetNumSymbols) {  // :416-420
+    if (c.resetNumSymbols && !cont) {  // :416-420
         ctl_linfit_reset(c, lim.fit_cap, nullptr, nullptr, true);
         c.resetNumSymbols = false;
     }
-    if (c.resetPhaseAvg) {  // :421-426
+    if (c.resetPhaseAvg && !cont) {  // :421-426
         uint64_t numPts = c.props.phaseAvg;
         ctl_linfit_reset(c, lim.fit_cap, &numPts, nullptr, false);
         c.resetPhaseAvg = false;
@@ -216,6 +221,12 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
     plan.ring_src = c.ring_src;
     plan.count0 = (uint32_t)c.count;
 
+    // LinearFit::count standing at 1048576: the next next() opens with reset() (cpp/psk_soft.cpp:51-52) -- the sums rebuilt from
+    // yvals, count = 0 -- which is what a plan flagged LF_RECOMPUTE has the kernels do before the call's first symbol
+    if (c.lf_count == kResyncCount && !c.lf_recompute_pending) {
+        c.lf_recompute_pending = true;
+        c.lf_count = 0;
+    }
     uint64_t n_out = 0;
     bool any_front = false;  // (regular window mode) the window class has no wave-scan instantiation
     if (S == 1) {

@@ -65,7 +65,7 @@ PSK_DEV void call_epilogue(const ChanPlan &p, ChanState *st, float *yv, uint32_t
     float pe = cy.est;
     const float wrapValue = (float)(kTwoPi * (double)p.M);
     uint32_t count1 = 0;
-    if (wrap_test(pe, wrapValue)) {
+    if (!(p.lf_flags & PLAN_NO_WRAP) && wrap_test(pe, wrapValue)) {
         float qv = pe / wrapValue;
         long long numWraps = to_long_x86(__builtin_round((double)qv));
         float cst = (float)numWraps * wrapValue;

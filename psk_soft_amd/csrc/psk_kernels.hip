@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
     if (lane == 0) {
         // end-of-call wrap, cpp/psk_soft.cpp:592-603
         const float wrapValue = (float)(kTwoPi * (double)p.M);
-        if (wrap_test(E.pe, wrapValue)) {
+        if (!(p.lf_flags & PLAN_NO_WRAP) && wrap_test(E.pe, wrapValue)) {
             float qv = E.pe / wrapValue;
             long long numWraps = to_long_x86(__builtin_round((double)qv));
             E.pe = E.fit.subtract_const((float)numWraps * wrapValue);

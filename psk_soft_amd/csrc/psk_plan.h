@@ -35,6 +35,9 @@ enum LfFlags : uint32_t {
     // the time-tiled kernels, behind the front stage that takes samplesPerBaud and numAvg at run time (psk_tile.hip:
     // psk_tile_front_any_kernel); what that hands over is the reference-order kernel's
     PLAN_ANYFRONT = 16u,
+    // a piece of a call the library has cut (more than 2^20 symbols: psk_capi.cpp) that is not the call's last: the end-of-call
+    // wrap of the phase estimate (cpp/psk_soft.cpp:592-603) belongs to the end of the CALL
+    PLAN_NO_WRAP = 32u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582

@@ -676,15 +676,19 @@ hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, ui
 {
     if (!nch || !max_tiles)
         return hipSuccess;
-    if (max_S <= 64u)
-        hipLaunchKernelGGL(psk_tile_front_any_kernel<1>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap,
-                           tiles, t_raw, t_s, pf_chan);
-    else if (max_S <= 256u)
-        hipLaunchKernelGGL(psk_tile_front_any_kernel<4>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap,
-                           tiles, t_raw, t_s, pf_chan);
-    else
-        hipLaunchKernelGGL(psk_tile_front_any_kernel<kAnyPhases>, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings,
-                           ring_cap, tiles, t_raw, t_s, pf_chan);
+    // (the channels of a launch are the grid's y dimension, 65535 at most: a larger class goes out in slices of its list)
+    for (uint32_t off = 0; off < nch; off += kGridYMax) {
+        const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
+        if (max_S <= 64u)
+            hipLaunchKernelGGL(psk_tile_front_any_kernel<1>, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states, rings,
+                               ring_cap, tiles, t_raw, t_s, pf_chan);
+        else if (max_S <= 256u)
+            hipLaunchKernelGGL(psk_tile_front_any_kernel<4>, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states, rings,
+                               ring_cap, tiles, t_raw, t_s, pf_chan);
+        else
+            hipLaunchKernelGGL(psk_tile_front_any_kernel<kAnyPhases>, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states,
+                               rings, ring_cap, tiles, t_raw, t_s, pf_chan);
+    }
     return hipGetLastError();
 }
 
@@ -710,21 +714,27 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
 {
     if (!nch || !max_tiles)
         return hipSuccess;
-    const dim3 grid(max_tiles, nch), wave(kWave);
+    const dim3 wave(kWave);
     static LdsGrant granted_b;
     if (const hipError_t e = lds_grant(reinterpret_cast<const void *>(&pf_begin_kernel), sizeof(float) * (size_t)y_len, granted_b))
         return e;
-    hipLaunchKernelGGL(pf_begin_kernel, dim3(nch), wave, sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, yvs, fit_cap, y_len, sc);
-    hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc);
-    for (int round = 0; round <= (second_round ? 1 : 0); round++) {
-        if (round)
-            hipLaunchKernelGGL(pf_retry_kernel, dim3(nch), wave, 0, stream, plans, list, sc);
-        hipLaunchKernelGGL(pf_y_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, sc, round);
-        hipLaunchKernelGGL(pf_ydiff_kernel, grid, wave, 0, stream, plans, list, ch0, yvs, fit_cap, sc, round);
-        hipLaunchKernelGGL(pf_ysum_kernel, grid, wave, 0, stream, plans, list, ch0, states, yvs, fit_cap, sc, round);
-        hipLaunchKernelGGL(pf_xblock_kernel, grid, wave, 0, stream, plans, list, ch0, states, sc, round);
-        hipLaunchKernelGGL(pf_xwalk_kernel, dim3(nch), wave, 0, stream, plans, list, sc.blk, sc, round);
-        hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, list, ch0, states, t_raw, t_est, sc, round);
+    // (channels are the grid's y dimension: slices of 65535; the channels of different slices have nothing to do with one another)
+    for (uint32_t off = 0; off < nch; off += kGridYMax) {
+        const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
+        const uint32_t *const l = list + off;
+        const dim3 grid(max_tiles, n);
+        hipLaunchKernelGGL(pf_begin_kernel, dim3(n), wave, sizeof(float) * (size_t)y_len, stream, plans, l, ch0, states, yvs, fit_cap, y_len, sc);
+        hipLaunchKernelGGL(pf_unwrap_kernel, grid, wave, 0, stream, plans, l, ch0, states, t_raw, sc);
+        for (int round = 0; round <= (second_round ? 1 : 0); round++) {
+            if (round)
+                hipLaunchKernelGGL(pf_retry_kernel, dim3(n), wave, 0, stream, plans, l, sc);
+            hipLaunchKernelGGL(pf_y_kernel, grid, wave, 0, stream, plans, l, ch0, states, t_raw, sc, round);
+            hipLaunchKernelGGL(pf_ydiff_kernel, grid, wave, 0, stream, plans, l, ch0, yvs, fit_cap, sc, round);
+            hipLaunchKernelGGL(pf_ysum_kernel, grid, wave, 0, stream, plans, l, ch0, states, yvs, fit_cap, sc, round);
+            hipLaunchKernelGGL(pf_xblock_kernel, grid, wave, 0, stream, plans, l, ch0, states, sc, round);
+            hipLaunchKernelGGL(pf_xwalk_kernel, dim3(n), wave, 0, stream, plans, l, sc.blk, sc, round);
+            hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, l, ch0, states, t_raw, t_est, sc, round);
+        }
     }
     return hipGetLastError();
 }
@@ -734,7 +744,10 @@ hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_
 {
     if (!nch || !max_tiles)
         return hipSuccess;
-    hipLaunchKernelGGL(psk_tile_back_kernel, dim3(max_tiles, nch), dim3(kWave), 0, stream, plans, list, ch0, states, tiles, t_s, t_est);
+    for (uint32_t off = 0; off < nch; off += kGridYMax) {
+        const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
+        hipLaunchKernelGGL(psk_tile_back_kernel, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states, tiles, t_s, t_est);
+    }
     return hipGetLastError();
 }
 

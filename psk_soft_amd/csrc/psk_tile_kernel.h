@@ -31,6 +31,7 @@
 namespace psk {
 
 constexpr uint32_t kGuardTiled = 4u;  // ChanState::guard: the time-tiled kernels finished this call
+constexpr uint32_t kGridYMax = 65535u;  // channels of one launch of the kernels whose grid is (tiles, channels)
 
 PSK_DEV bool tile_plan_mine(const ChanPlan &p) { return p.mode == PLAN_FAST && (p.lf_flags & PLAN_TILED) && p.n_out != 0; }
 
@@ -121,8 +122,11 @@ hipError_t launch_tile_front_inst(PSK_TILE_FRONT_ARGS)
     if (!nch || !max_tiles)
         return hipSuccess;
     const size_t lds_bytes = sizeof(float) * (ering_dynamic(SV) ? (size_t)SV * r_len : 0);
-    hipLaunchKernelGGL((psk_tile_front_kernel<SV, HV>), dim3(max_tiles, nch), dim3(kWave), lds_bytes, stream, plans, list, ch0, states,
-                       rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan);
+    for (uint32_t off = 0; off < nch; off += kGridYMax) {  // (channels are the grid's y dimension: slices of 65535)
+        const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
+        hipLaunchKernelGGL((psk_tile_front_kernel<SV, HV>), dim3(max_tiles, n), dim3(kWave), lds_bytes, stream, plans, list + off, ch0, states,
+                           rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan);
+    }
     return hipGetLastError();
 }
 

@@ -730,7 +730,9 @@ def test_samples_per_baud_1_leaves_the_carried_window_alone(oracle_mod, path):
 
 def test_call_longer_than_resync_count(oracle_mod):
     """More than 1048576 symbols in ONE call: the reference resyncs symbolEnergy and the fit sums
-    in mid-loop (cpp/psk_soft.cpp:51-52, 582-583); such calls go to the reference-order kernel."""
+    in mid-loop (cpp/psk_soft.cpp:51-52, 582-583).  The library cuts such a call at those boundaries and runs the
+    pieces as continuations of one serviceFunction() call on the wave-scan / time-tiled kernels (round 2: the
+    reference-order kernel, 4.7 us per symbol)."""
     n_sym = 1048576 + 3000
     S = 2
     rng = np.random.default_rng(9)
@@ -747,8 +749,42 @@ def test_call_longer_than_resync_count(oracle_mod):
     h = _handle(max_packet_complex=iq.size // 2)
     h.configure(0, [props])
     got = run_gpu(h, 0, iq, 0.01)
-    assert h.stats()["channels_sequential"] == 1
+    st = h.stats()
+    assert st["channels_sequential"] == 0 and st["channels_fast"] == 1, st
     assert_parity(got, ref, "long call")
+    h.close()
+
+
+@pytest.mark.parametrize("S,M,A,n_ph,n_sym", [(2, 4, 100, 50, (1 << 21) + 12345), (8, 8, 25, 200, (1 << 20) + 77)])
+def test_long_calls_in_pieces_with_carried_state(oracle_mod, S, M, A, n_ph, n_sym):
+    """Calls of more than 2^20 symbols, a short call in front (so that the long one starts from a filled window and a
+    fit history) and one behind (the state the pieces leave is the state the reference is in): all four streams bit for
+    bit, nothing on the reference-order kernel.  The 2^21-symbol call at samplesPerBaud 2 must take milliseconds."""
+    import time
+
+    from psk_soft_amd.stimulus import synth_channel
+
+    n0, n2 = 5000, 7000
+    iq = synth_channel(4242 + S, M, S, (n0 + n2) * S + n_sym * S)
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n_ph)
+    cuts = [0, n0 * S, n0 * S + n_sym * S, iq.size // 2]
+    o = oracle_mod.OracleComponent()
+    for k, v in props.items():
+        setattr(o, k, v)
+    h = _handle(max_packet_complex=n_sym * S + 16, max_phase_avg=256)
+    h.configure(0, [props])
+    for k in range(3):
+        x = iq[2 * cuts[k] : 2 * cuts[k + 1]]
+        r = o.service(x, 0.01, sriChanged=(k == 0))
+        t0 = time.perf_counter()
+        g = h.process_host(0, [dict(data=x, xdelta=0.01, sriChanged=(k == 0))])[0]
+        dt = time.perf_counter() - t0
+        st = h.stats()
+        assert st["channels_sequential"] == 0 and st["channels_fast"] == 1, (k, st)
+        assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "S=%d call %d" % (S, k))
+        if k == 1:
+            assert r.phase.size > (1 << 20)
+            assert dt < 2.0, "a %d-symbol call took %.2f s" % (r.phase.size, dt)
     h.close()
 
 

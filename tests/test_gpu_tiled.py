@@ -377,3 +377,23 @@ def test_run_time_front_hands_over(oracle_mod):
         assert st["channels_sequential"] == 1 and st["channels_guard"] == 1, st
         assert_parity(got, ref, "S%d" % S)
         h.close()
+
+
+def test_more_channels_than_a_grid_dimension(oracle_mod):
+    """A window class that always goes through the time-tiled kernels (samplesPerBaud 40: no wave-scan instantiation) with more
+    channels than the y dimension of a grid holds (65535): the launches go out in slices of the class's channel list."""
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    C, S, M, A, N = 66000, 40, 4, 4, 2400
+    base = [synth_channel(900 + c, M, S, N) for c in range(8)]
+    h = pl.Handle(C, device=0, max_window_samples=256, max_phase_avg=64)
+    h.configure_all(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=20)
+    pkts = [dict(data=base[c % 8], xdelta=0.01, sriChanged=True) for c in range(C)]
+    res = h.process_host(0, pkts)
+    st = h.stats()
+    assert st["channels_fast"] == C and st["channels_tiled"] == C and st["channels_sequential"] == 0, st
+    for c in (0, 1, 7, 65534, 65535, 65536, C - 1):
+        ref = oracle_run(oracle_mod, base[c % 8], dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=20))
+        assert_parity(res[c], ref, "channel %d of %d" % (c, C))
+    h.close()
