@@ -215,6 +215,7 @@ def few_channels(pl, torch, dev, dev_index, M, S, numAvg, phaseAvg, check, C=1, 
         out[c].soft, out[c].bits, out[c].phase, out[c].sampleIndex = soft[c].data_ptr(), bits[c].data_ptr(), phase[c].data_ptr(), sidx[c].data_ptr()
         out[c].cap_symbols = cap
     stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))  # (the stimulus is generated on torch's current stream)
     res, warm, steps = {}, 3, 10
     for mode, key in modes:
         h = pl.Handle(C, device=dev_index)
@@ -296,6 +297,7 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
         out[c].soft, out[c].bits, out[c].phase, out[c].sampleIndex = soft[c].data_ptr(), bits[c].data_ptr(), phase[c].data_ptr(), sidx[c].data_ptr()
         out[c].cap_symbols = cap
     stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))  # (the stimulus is generated on torch's current stream)
     for _ in range(warmup):
         h.process_device(0, pk, out, stream=stream.cuda_stream)
     torch.cuda.synchronize(dev)
@@ -328,10 +330,16 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
             for _ in range(warmup + steps):
                 r = comp.service(x, 0.01, sriChanged=False)
             b = {2: 1, 4: 2, 8: 3}.get(props[c]["constelationSize"], 0)
-            for g, w, dt in ((soft[c, : 2 * n_out], r.soft, np.uint32), (phase[c, :n_out], r.phase, np.uint32),
-                             (bits[c, : b * n_out], r.bits, np.int16), (sidx[c, :n_out], r.index, np.int16)):
+            for nm, g, w, dt in (("soft", soft[c, : 2 * n_out], r.soft, np.uint32), ("phase", phase[c, :n_out], r.phase, np.uint32),
+                                 ("bits", bits[c, : b * n_out], r.bits, np.int16), ("sampleIndex", sidx[c, :n_out], r.index, np.int16)):
                 ft = np.float32 if dt is np.uint32 else np.int16
-                same = same and np.array_equal(g.cpu().numpy().view(dt), np.ascontiguousarray(w, ft).view(dt))
+                ga, wa = g.cpu().numpy().view(dt), np.ascontiguousarray(w, ft).view(dt)
+                ok = ga.size == wa.size and np.array_equal(ga, wa)
+                if not ok:  # (say where, before the assertion below ends the run)
+                    d = np.nonzero(ga != wa)[0] if ga.size == wa.size else np.zeros(0, int)
+                    sys.stderr.write("%s: channel %d, %s: %d of %d values differ (sizes %d / %d), first at %s\n"
+                                     % (name[:40], c, nm, d.size, wa.size, ga.size, wa.size, d[:4].tolist()))
+                same = same and ok
         res["check"] = {"channels": [0, C - 1], "calls_replayed": warmup + steps, "all_four_streams_bit_identical": bool(same)}
         assert same, "%s: the HIP path differs from the oracle" % name
     h.close()

@@ -52,6 +52,7 @@ hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_
 namespace {
 
 thread_local std::string g_last_error;
+thread_local bool g_long_call = false;  // process_round's note to psk_soft_process_device: plan the call in pieces
 
 psk_soft_status fail(psk_soft_status st, const std::string &msg)
 {
@@ -158,6 +159,7 @@ struct PlanSummary {
     uint32_t bad = 0;  // first refused channel (index into the batch)
     int why = 0;       // 0: status of plan_call, 1: samplesPerBaud > 1024, 2: alignment
     bool any = false, any_emit = false, any_seq = false, any_quiet = false;
+    bool long_call = false;  // some channel's call is planned for the reference-order kernel only because of its length
     bool need_SH[33][17] = {};
     uint32_t cnt_SH[33][17] = {}, cnt_quiet = 0;  // channels per launch: each launch gets a compact list of its own
     // LDS rings of a launch are sized for the largest phaseAvg / numAvg among its channels: a ring of
@@ -544,6 +546,9 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 }
             } else {
                 r.any_seq = true;
+                if (!lim.force_seq && p.lf_n <= lim.fast_fit_max &&
+                    (p.n_out > psk::kResyncCount || (uint64_t)p.lf_count0 + p.n_out > psk::kResyncCount))
+                    r.long_call = true;
             }
         }
     };
@@ -553,6 +558,10 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // the whole pass (spinning instead would burn cores between packets).
     PlanSummary res;
     plan_range(0, nch, res);
+    if (res.st == PSK_SOFT_OK && res.long_call && !cont) {
+        g_long_call = true;  // (nothing committed, nothing enqueued: the caller cuts the call into pieces)
+        return PSK_SOFT_OK;
+    }
     if (res.st != PSK_SOFT_OK) {
         if (res.why == 1)
             return fail(PSK_SOFT_ERR_LIMIT, "samplesPerBaud > 1024");
@@ -879,25 +888,15 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
 {
     if (!h || !pkts || !outs || !nch || (uint64_t)ch0 + nch > h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_process: bad arguments");
-    // symbols a packet of n samples can emit at most, and how many the kernels take in one piece
-    auto piece_symbols = [&](uint32_t i) -> uint64_t {
-        const psk::ChanCtl &c = h->ctl[ch0 + i];
-        const uint64_t used = (c.lf_recompute_pending || c.lf_count >= psk::kResyncCount) ? 0 : c.lf_count;
-        return psk::kResyncCount - used;
-    };
-    bool any_long = false;
-    if (!h->lim.force_seq)
-        for (uint32_t i = 0; i < nch && !any_long; i++) {
-            if (!pkts[i].present || pkts[i].sri_mode != 1)
-                continue;
-            const uint64_t S = h->ctl[ch0 + i].props.samplesPerBaud ? h->ctl[ch0 + i].props.samplesPerBaud : 1;
-            // (a call resets LinearFit::count at its top whenever the SRI block runs, quirk Q2: only the packet length matters then;
-            // the count carried in is the conservative bound)
-            any_long = (pkts[i].n_floats / 2) / S + h->ctl[ch0 + i].props.numAvg + 2 > piece_symbols(i) ||
-                       (pkts[i].n_floats / 2) / S + 2 > psk::kResyncCount;
-        }
-    if (!any_long)
-        return process_round(h, ch0, nch, pkts, outs, stream_v, nullptr);
+    // (the ordinary call is planned as it is; the plan pass itself says when a channel's call is too long for one piece --
+    // nothing is committed or enqueued then)
+    g_long_call = false;
+    {
+        const psk_soft_status st = process_round(h, ch0, nch, pkts, outs, stream_v, nullptr);
+        if (st != PSK_SOFT_OK || !g_long_call)
+            return st;
+        g_long_call = false;
+    }
 
     // ---- pieces ----
     std::vector<psk_soft_packet_t> pk(pkts, pkts + nch);

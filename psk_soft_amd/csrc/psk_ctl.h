@@ -89,6 +89,25 @@ inline bool any_front_has(uint32_t S) { return S >= 2 && S <= 1024; }
 // history blocks of the instantiation that takes a window of numAvg symbols
 inline int fast_hist_blocks(uint32_t A) { return A <= 128u ? 1 : A <= 256u ? 2 : A <= 512u ? 4 : 8; }
 
+// a / d and a % d for the symbol clock: 64-bit divisions cost the control plane more than everything else in plan_call (four
+// of them per channel and call); samplesPerBaud is a power of two more often than not, and the operands fit 32 bits otherwise
+inline uint64_t ctl_div(uint64_t a, uint64_t d)
+{
+    if ((d & (d - 1)) == 0)
+        return a >> __builtin_ctzll(d);
+    if (((a | d) >> 32) == 0)
+        return (uint32_t)a / (uint32_t)d;
+    return a / d;
+}
+inline uint64_t ctl_mod(uint64_t a, uint64_t d)
+{
+    if ((d & (d - 1)) == 0)
+        return a & (d - 1);
+    if (((a | d) >> 32) == 0)
+        return (uint32_t)a % (uint32_t)d;
+    return a % d;
+}
+
 // LinearFit::reset(numPts, sampleRate, forceHistoryClear) on the control state,
 // cpp/psk_soft.cpp:89-124.  Returns true (the sums must be rebuilt).
 inline void ctl_linfit_reset(ChanCtl &c, uint32_t fit_cap, const uint64_t *numPts, const float *sampleRate,
@@ -188,7 +207,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         c.symEnergySize = S;
         if (c.ring_len > D)
             c.ring_len = D;
-        c.index = c.ring_len % S;
+        c.index = ctl_mod(c.ring_len, S);
         c.count = 0;
         c.resetSamplesPerBaud = false;
         resynced = true;
@@ -248,7 +267,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         // window already full (or numAvg==0): size()==numDataPts can never hold again; the
         // deque only grows.  The device ring keeps the oldest ring_cap samples, which is all a
         // later resyncEnergy() can keep (it trims from the back, :622-626).
-        c.index = (c.index + N) % S;
+        c.index = ctl_mod(c.index + N, S);
         c.ring_len += N;
         uint64_t dev1 = c.ring_len < lim.ring_cap ? c.ring_len : lim.ring_cap;
         plan.ring_len1 = (uint32_t)dev1;
@@ -259,12 +278,12 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         // index == size % S and the ring starts on a symbol boundary.
         (void)resynced;
         const uint64_t total = c.ring_len + N;
-        const uint64_t complete = total / S;
+        const uint64_t complete = ctl_div(total, S);
         const uint64_t A = c.props.numAvg;  // A >= 1 here because D > ring_len >= 0
         n_out = complete >= A ? complete - (A - 1) : 0;
         // every emission pops S samples (:579-580)
         c.ring_len = total - n_out * S;
-        c.index = c.ring_len % S;
+        c.index = ctl_mod(c.ring_len, S);
         c.count = (c.count + n_out) % kResyncCount;  // :581-583
         plan.ring_len1 = (uint32_t)c.ring_len;
         any_front = !fast_kernel_has((uint32_t)S, (uint32_t)A);
@@ -296,7 +315,7 @@ inline psk_soft_status plan_call(ChanCtl &c, const Limits &lim, const psk_soft_p
         uint64_t grow = c.lf_len + n_out;
         uint64_t new_len = grow < c.lf_n ? grow : c.lf_n;
         uint64_t dropped = grow - new_len;
-        c.lf_head = (uint32_t)((c.lf_head + dropped) % lim.fit_cap);
+        c.lf_head = (uint32_t)ctl_mod(c.lf_head + dropped, lim.fit_cap);
         c.lf_len = new_len;
         // count==1048576 -> reset() -> count=0 at the top of next() (:51-52)
         uint64_t cnt = (plan.lf_flags & LF_RECOMPUTE) ? 0 : c.lf_count;
