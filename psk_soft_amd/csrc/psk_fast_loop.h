@@ -241,7 +241,11 @@ PSK_DEV void load_block(const XView &X, long long cblk, uint32_t A, long long ta
             (typename F4Ptr<packet_global(S)>::type)base + (uint32_t)lane * (uint32_t)S;
 #pragma unroll
         for (int k = 0; k < S; k++) {
+#if PSK_NT_LOAD
+            const f4g t = __builtin_nontemporal_load(q + k);
+#else
             const f4g t = q[k];
+#endif
             x[(2 * k) / S][(2 * k) % S] = make_float2(t.x, t.y);
             x[(2 * k + 1) / S][(2 * k + 1) % S] = make_float2(t.z, t.w);
         }

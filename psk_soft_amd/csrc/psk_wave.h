@@ -214,13 +214,25 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef short s2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef short s4u __attribute__((ext_vector_type(4), aligned(4)));
 PSK_DEV void store_f4u(float *p, f4u v) { *reinterpret_cast<f4u *>(p) = v; }
-PSK_DEV void store_f4u(PSK_GLOBAL float *p, f4u v) { *(PSK_GLOBAL f4u *)p = v; }
+// PSK_NT_STORE / PSK_NT_LOAD (experiments): the output rows / the packet with the non-temporal hint (written once, read once)
+#ifndef PSK_NT_STORE
+#define PSK_NT_STORE 0
+#endif
+#ifndef PSK_NT_LOAD
+#define PSK_NT_LOAD 0
+#endif
+#if PSK_NT_STORE
+#define PSK_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define PSK_ST(ptr, v) (*(ptr) = (v))
+#endif
+PSK_DEV void store_f4u(PSK_GLOBAL float *p, f4u v) { PSK_ST((PSK_GLOBAL f4u *)p, v); }
 PSK_DEV void store_f2u(float *p, f2u v) { *reinterpret_cast<f2u *>(p) = v; }
-PSK_DEV void store_f2u(PSK_GLOBAL float *p, f2u v) { *(PSK_GLOBAL f2u *)p = v; }
+PSK_DEV void store_f2u(PSK_GLOBAL float *p, f2u v) { PSK_ST((PSK_GLOBAL f2u *)p, v); }
 PSK_DEV void store_s2u(int16_t *p, s2u v) { *reinterpret_cast<s2u *>(p) = v; }
-PSK_DEV void store_s2u(PSK_GLOBAL int16_t *p, s2u v) { *(PSK_GLOBAL s2u *)p = v; }
+PSK_DEV void store_s2u(PSK_GLOBAL int16_t *p, s2u v) { PSK_ST((PSK_GLOBAL s2u *)p, v); }
 PSK_DEV void store_s4u(int16_t *p, s4u v) { *reinterpret_cast<s4u *>(p) = v; }
-PSK_DEV void store_s4u(PSK_GLOBAL int16_t *p, s4u v) { *(PSK_GLOBAL s4u *)p = v; }
+PSK_DEV void store_s4u(PSK_GLOBAL int16_t *p, s4u v) { PSK_ST((PSK_GLOBAL s4u *)p, v); }
 struct XView {
     const f2g *ring;
     const f2g *in;
