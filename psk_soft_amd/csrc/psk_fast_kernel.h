@@ -137,7 +137,7 @@ PSK_DEV void call_epilogue(const ChanPlan &p, ChanState *st, float *yv, uint32_t
 #define PSK_WAVES_PER_SIMD_H2 1
 #endif
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : (HV == 2 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD_H2 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : (HV == 2 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD_H2 : (HV == 4 && SV <= 8 && !EXACT && PSK_DBUF) ? 2 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, ((HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
     const ChanPlan &p = plans[bi];
     if (p.mode != PLAN_FAST)
         return;
-    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV))
+    if (SV == 0 ? (p.n_out != 0) : (p.n_out == 0 || p.S != (uint32_t)SV || (HV == 0 ? p.A <= (uint32_t)kB : hist_blocks_for(p.A) != HV)))
         return;
     if (EXACT && states[ch0 + bi].guard != 1u)
         return;  // the screened kernel finished this channel's call

@@ -48,6 +48,12 @@ namespace psk {
 constexpr int kR = 2;           // symbols per lane per block
 constexpr int kB = kWave * kR;  // symbols per block
 constexpr int kMaxUnwrapPasses = 160;
+#ifndef PSK_WIDE_FIRST
+#define PSK_WIDE_FIRST 1
+#endif
+#ifndef PSK_DBUF
+#define PSK_DBUF 1
+#endif
 constexpr int kScreenRefresh = 64;  // blocks between refreshes of the float window sums
 
 struct FastCarry {
@@ -795,6 +801,31 @@ PSK_DEV float window_end_f32(const BlockKeep<S> (&hist)[H], uint32_t A, int lane
     return read_lane(wave_scan_f32(acc), 63);
 }
 
+// the same without a history (H == 0): the window's symbols read again, newest block first like the register variant
+template <int S>
+PSK_DEV void window_end_reread_f32(const XView &X, int c, int c_begin, uint32_t A, long long tau_last, int lane, float (&W)[S])
+{
+    const int u = (int)((A - 1) / kB), v = (int)A - u * kB;  // 1 <= v <= kB
+    float acc[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) acc[k] = 0.0f;
+    for (int j = 0; j <= u; j++) {
+        float2 x[kR][S];
+        load_block<S>(X, (long long)(c - j), A, (long long)c_begin * kB, tau_last, lane, x);
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            const bool in = j < u || 2 * lane + r >= kB - v;
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                const float e = norm_f(x[r][k].x, x[r][k].y);
+                acc[k] += in ? e : 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < S; k++) W[k] = read_lane(wave_scan_f32(acc[k]), 63);
+}
+
 // the same for numAvg <= 128 from the LDS ring: the window is the positions >= kB - A of the block
 // at `base`
 template <bool DYN>
@@ -1205,10 +1236,36 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
 
     // ---- prologue: the first A-1 symbols (the carried window) as "blocks" -H .. -1:
     //      W_k(-1) = their energy sums (= resyncEnergy, reference cpp/psk_soft.cpp:619-636) ----
-    BlockKeep<S> hist[H];
+    //      H == 0 (REREAD): no history at all.  A window longer than a block costs 22 registers per block of history
+    //      (numAvg 400: 88, two waves on a SIMD instead of four); this variant reads the samples of the symbols that LEAVE the
+    //      window a second time instead -- they passed through numAvg symbols ago, L2 / Infinity Cache territory -- and
+    //      computes their energies again (the same float operation on the same floats: the same energies).
+    constexpr bool REREAD = (H == 0);
+    BlockKeep<S> hist[H ? H : 1];
     double Wc[S];  // EXACT: the exact carried window sums
     float Wf[S];   // screened: their float shadow
-    {
+    if constexpr (REREAD) {
+        static_assert(!REREAD || !EXACT, "the exact tier keeps its history in registers");
+        double acc[S];
+#pragma unroll
+        for (int k = 0; k < S; k++) acc[k] = 0.0;
+        // (block -(h+1) holds the symbols tau = kB * (c_begin - h - 1) + s + A - 1 of the carried window [kB * c_begin, + A - 2]:
+        // something for h + 1 <= (A + 126) / kB; the same order of additions as the register variant)
+        for (int h = (int)((A + 126u) / (uint32_t)kB) - 1; h >= 0; h--) {
+            float2 x[kR][S];
+            load_block<S>(X, (long long)c_begin - (long long)(h + 1), A, (long long)c_begin * kB, (long long)c_begin * kB + (long long)A - 2, lane, x);
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+#pragma unroll
+                for (int k = 0; k < S; k++) acc[k] += (double)norm_f(x[r][k].x, x[r][k].y);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S; k++) {
+            Wc[k] = wave_sum_f64(acc[k]);
+            Wf[k] = uni((float)Wc[k]);
+        }
+    } else {
         double acc[S];
 #pragma unroll
         for (int k = 0; k < S; k++) acc[k] = 0.0;
@@ -1255,7 +1312,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     const RotParam rotE = rot_param(lane, A);
     const RotParam rotP = rot_param(lane, A - 1);
     // (numAvg <= 128: both fetches reach at most one block back, known at compile time)
-    const int uE = (H == 1) ? 0 : rotE.u, uP = (H == 1) ? 0 : rotP.u;
+    const int uE = (H <= 1) ? 0 : rotE.u, uP = (H <= 1) ? 0 : rotP.u;
 
     // steady-state fit constants
     float den_s = cy.den, xavg_s = cy.xavg;
@@ -1284,6 +1341,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     // row once a block, and takes the priority of its rank: most work left, highest priority.  The waves of a SIMD then
     // advance together and end together, whatever slows one of them down (an older neighbour, blocks that need the
     // lane-after-lane chain, exact timing redos).  Priorities change no result; stale or missing table entries only cost speed.
+    // A batch that mixes window classes: the waves of the long windows (two to a SIMD, or one beside two of the short class)
+    // post their count with a bias that ranks them in front of every short-window wave.  They are the launch's long pole --
+    // register-bound residency, so a second round of short-window waves has to wait for their registers -- and the sooner
+    // they are through, the sooner the machine is back to four waves a SIMD.
+    constexpr uint32_t kPaceBias = (PSK_WIDE_FIRST && H >= 2) ? (1u << 24) : 0u;
     uint32_t pace = 0u;
     if constexpr (PSK_PACE_ON(FRONT, EXACT))
         pace = pace_key();
@@ -1295,6 +1357,16 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         default: __builtin_amdgcn_s_setprio(3); break;
         }
     };
+    // Windows longer than a block (H >= 2) run two waves to a SIMD, 172 ... 230 registers each: too few waves to hide the
+    // latency of a block's loads behind each other's arithmetic, and registers to spare (256 a wave at that residency).  There
+    // the samples of block c + 1 are requested before block c is worked on.  (At numAvg <= 128, four waves to a SIMD and not
+    // a register free, the same was measured 1.5 % slower.)
+    constexpr bool DBUF = PSK_DBUF && H >= 2 && !FRONT && !EXACT;
+    float2 xnext[kR][S];
+    if constexpr (DBUF) {
+        if (c_begin < n_blocks)
+            load_block<S>(X, (long long)c_begin, A, 0, tau_last, lane, xnext);
+    }
     for (int c = c_begin; c < n_blocks; c++) {
         // Without pacing: the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
@@ -1307,10 +1379,20 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if (pace_now)
             pace_row = pace_fetch(pace, lane);  // (in front of the block's loads: it is back before they are)
         float2 xn[kR][S];
-        load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+        if constexpr (DBUF) {
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+#pragma unroll
+                for (int k = 0; k < S; k++) xn[r][k] = xnext[r][k];
+            }
+            if (c + 1 < n_blocks)  // (wave-uniform)
+                load_block<S>(X, (long long)(c + 1), A, 0, tau_last, lane, xnext);
+        } else {
+            load_block<S>(X, (long long)c, A, 0, tau_last, lane, xn);
+        }
         if (pace_now) {
-            pace_post(pace, (uint32_t)(n_blocks - c), lane);  // (behind them: nothing waits for a store)
-            set_prio_dyn(pace_rank(pace, pace_row, (uint32_t)(n_blocks - c), lane));
+            pace_post(pace, (uint32_t)(n_blocks - c) + kPaceBias, lane);  // (behind them: nothing waits for a store)
+            set_prio_dyn(pace_rank(pace, pace_row, (uint32_t)(n_blocks - c) + kPaceBias, lane));
         }
 
         const int i0 = c * kB + 2 * lane;  // first output symbol of this lane
@@ -1320,6 +1402,31 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         const int rem = n_out - c * kB;
         const int nvalid = rem < kB ? rem : kB;  // valid positions of this block
         const int lane_last = (nvalid - 1) >> 1, r_last = (nvalid - 1) & 1;
+
+        // REREAD: the symbols that leave the window at this block's positions -- output symbol i drops symbol i - 1 -- and,
+        // for the symbols being output, the sample at the timing index their lane chose a block ago (verified below, like
+        // the kept samples of the other variants); all of it requested here, behind the new symbols
+        float e_old[kR][S];
+        float px[kR], py[kR];
+        int pkk[kR];
+        if constexpr (REREAD) {
+            float2 xo[kR][S];
+            load_block<S>(X, (long long)c, 0u, (long long)c_begin * kB, tau_last, lane, xo);  // tau = kB * c + s - 1
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                const uint64_t j = (uint64_t)(c * kB + 2 * lane + r) * S + (uint64_t)kpred[r];  // (exists: A > kB)
+                const f2g *q = j < X.L0 ? X.ring + j : X.in + (j - X.L0);
+                const f2g g = *mem_ptr<packet_global(S)>(q);
+                px[r] = g.x;
+                py[r] = g.y;
+                pkk[r] = kpred[r];
+            }
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+#pragma unroll
+                for (int k = 0; k < S; k++) e_old[r][k] = norm_f(xo[r][k].x, xo[r][k].y);
+            }
+        }
 
         // ================= timing recovery =================
         // energies of the new symbols; of their samples keep the one at the predicted timing index
@@ -1337,7 +1444,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             }
             cur.kp[r] = kpred[r];
         }
-        {
+        if constexpr (!REREAD) {
             const int k0u = __builtin_amdgcn_readfirstlane(kpred[0]), k1u = __builtin_amdgcn_readfirstlane(kpred[1]);
             if (PSK_SELECT_UNIFORM && vote_all(kpred[0] == k0u && kpred[1] == k1u)) {
                 cur.pk[0] = select_sample_uniform<S>(xn[0], k0u);
@@ -1349,8 +1456,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         }
         // energy of symbol i-1 for every phase (it entered the window A symbols before symbol
         // i+A-1 did): all cross-lane fetches issued back to back
-        float e_old[kR][S];
-        if constexpr (H == 1) {
+        if constexpr (REREAD) {
+        } else if constexpr (H == 1) {
             ering_put<S>(er, ring_base, lane, cur.e);
             wave_lds_fence();
             ering_get<S>(er, ring_base, lane, A, e_old);
@@ -1368,9 +1475,7 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             }
         }
         // the sample kept A-1 symbols ago for the symbol now being output, and the index it was kept at
-        float px[kR], py[kR];
-        int pkk[kR];
-        {
+        if constexpr (!REREAD) {
             float nx[kR], ox[kR], ny[kR], oy[kR];
             int nk[kR], ok2[kR];
 #pragma unroll
@@ -1543,9 +1648,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         }
 
         // history for the next block
+        if constexpr (!REREAD) {
 #pragma unroll
-        for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
-        hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
+            for (int h = H - 1; h > 0; h--) hist[h] = hist[h - 1];
+            hist[0] = cur;  // (numAvg <= 128: only the kept samples are used from it)
+        }
 
         // (a wave whose sums need the lane-after-lane chain -- a stationary carrier sitting at zero phase -- pays
         // ~2 us of pure latency per block there.  The launch waits for its slowest wave, so such a wave keeps a
@@ -1609,16 +1716,22 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
             // registers, so that their error bound does not grow with the length of the call
             if (since_refresh >= kScreenRefresh) {
                 float wm = 0.0f;
+                float wre[S];
+                if constexpr (REREAD)
+                    window_end_reread_f32<S>(X, c, c_begin, A, tau_last, lane, wre);
 #pragma unroll
                 for (int k = 0; k < S; k++) {
-                    if constexpr (H == 1)
+                    if constexpr (REREAD)
+                        Wf[k] = wre[k];
+                    else if constexpr (H == 1)
                         Wf[k] = window_end_ring_f32(er, ring_base, A, lane, k);
                     else
                         Wf[k] = window_end_f32<S, H>(hist, A, lane, k);
                     wm = __builtin_fmaxf(wm, Wf[k]);
                 }
                 wmax_prev = __builtin_fmaxf(wmax_prev, wm);
-                err_c = 16.0f * kU * wmax_prev;  // a 7-level float tree sum of non-negative terms
+                // (a 7-level float tree sum of non-negative terms; REREAD: two more additions per block of window in front of it)
+                err_c = (REREAD ? (float)(8u + 2u * ((A + 127u) / (uint32_t)kB)) : 16.0f) * kU * wmax_prev;
                 since_refresh = 0;
             }
         }

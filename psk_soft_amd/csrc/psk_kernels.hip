@@ -23,6 +23,7 @@
 //
 // Built with -ffp-contract=off (quirk Q9).  No MFMA: the path is a streaming complex-MAC
 // with O(1) flop/byte, bound by HBM.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -318,6 +319,7 @@ namespace psk {
 // (numAvg <= 128: the screened kernel settles near-ties itself; its exact-timing sibling takes the calls with
 // non-finite samples or a non-finite / astronomically large phase estimate in the channel state)
 #define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
+PSK_DECL(8, 0, 0)
 PSK_DECL_S(2)
 PSK_DECL_S(3)
 PSK_DECL_S(4)
@@ -373,6 +375,11 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
 {
     if (S == 0)
         return launch_fast_inst<0, 1, false>(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+    {
+        static const bool reread = [] { const char *e = getenv("PSK_SOFT_REREAD"); return e && e[0] == '1'; }();
+        if (reread && !exact && H > 1 && S == 8)
+            return launch_fast_S8_H0_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+    }
 #define PSK_CASE(Sv, Hv)                                                                                              \
     if (S == Sv && H == Hv)                                                                                           \
         return exact ? launch_fast_S##Sv##_H##Hv##_E1(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream) \

@@ -6,7 +6,7 @@ for mode in "" "--serial-classes"; do
   tag=mixed${mode:+_serial}
   out=$R/gpurun_out/$tag
   mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --mixed $mode --steps 6 --warmup 2 --no-cpu-baseline --no-check --no-few > $out/log.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --mixed $mode --steps 6 --warmup 2 --no-cpu-baseline --no-check --no-few --no-extra > $out/log.txt 2>&1
   tail -c 600 $out/log.txt | head -c 400; echo
   f=$(find $out -name "*kernel_trace.csv" | head -1)
   echo "== $tag"
