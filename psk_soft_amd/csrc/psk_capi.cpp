@@ -227,6 +227,16 @@ struct psk_soft_handle {
     std::vector<psk::ChanCtl> ctl_next;     // scratch of one call: planned on copies, committed on success
     std::vector<psk::ChanPlan> plans_dry;   // plans of a control-plane-only handle (no pinned slots)
     std::vector<uint32_t> last_mode;  // PlanMode of the last call, per channel (statistics)
+    // Uniform run of the control plane (the stamped path of process_round): the channels [uni_lo, uni_hi) are known to hold
+    // IDENTICAL control state.  While uni_lazy is set that state lives in uni_ctl / uni_mode alone and ctl[] / last_mode[] of
+    // the range are stale: every reader goes through ctl_sync() first, every writer through ctl_touch().
+    uint32_t uni_lo = 0, uni_hi = 0;
+    bool uni_lazy = false;
+    psk::ChanCtl uni_ctl;
+    uint32_t uni_mode = psk::PLAN_SKIP;
+    uint32_t mixed_lo = 0, mixed_hi = 0;  // a range that was compared and found mixed ...
+    int mixed_ttl = 0;                    // ... is not compared again for this many calls (or until something is configured)
+    int opt_stamp = 1;                    // PSK_SOFT_STAMP=0 (environment): every channel planned on its own (A/B runs, tests)
     // device memory
     psk::ChanState *d_state = nullptr;
     float2 *d_ring = nullptr;
@@ -271,6 +281,40 @@ struct psk_soft_handle {
     size_t stage_bytes = 32u << 20;  // input bytes per chunk (PSK_SOFT_STAGE_MB)
 };
 
+namespace {
+// the per-channel mirror brought up to date (see psk_soft_handle::uni_lazy)
+void ctl_sync(const psk_soft_handle *hc)
+{
+    psk_soft_handle *h = const_cast<psk_soft_handle *>(hc);
+    if (!h->uni_lazy)
+        return;
+    for (uint32_t i = h->uni_lo; i < h->uni_hi; i++) {
+        h->ctl[i] = h->uni_ctl;
+        h->last_mode[i] = h->uni_mode;
+    }
+    h->uni_lazy = false;
+}
+// ... and about to be changed channel by channel: nothing is known to be uniform any more
+void ctl_touch(psk_soft_handle *h)
+{
+    ctl_sync(h);
+    h->uni_lo = h->uni_hi = 0;
+    h->mixed_lo = h->mixed_hi = 0;
+    h->mixed_ttl = 0;
+}
+bool ctl_equal(const psk::ChanCtl &a, const psk::ChanCtl &b)
+{
+    return a.props.samplesPerBaud == b.props.samplesPerBaud && a.props.constelationSize == b.props.constelationSize &&
+           a.props.numAvg == b.props.numAvg && a.props.phaseAvg == b.props.phaseAvg &&
+           a.props.differentialDecoding == b.props.differentialDecoding && a.props.resetState == b.props.resetState &&
+           a.resetSamplesPerBaud == b.resetSamplesPerBaud && a.resetNumSymbols == b.resetNumSymbols && a.resetPhaseAvg == b.resetPhaseAvg &&
+           a.ring_len == b.ring_len && a.symEnergySize == b.symEnergySize && a.index == b.index && a.count == b.count &&
+           std::memcmp(&a.sampleRate, &b.sampleRate, sizeof(float)) == 0 && a.lf_n == b.lf_n &&
+           std::memcmp(&a.lf_xdelta, &b.lf_xdelta, sizeof(float)) == 0 && a.lf_len == b.lf_len && a.lf_count == b.lf_count &&
+           a.lf_head == b.lf_head && a.ring_src == b.ring_src && a.lf_recompute_pending == b.lf_recompute_pending;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t psk_soft_abi_version(void) { return PSK_SOFT_ABI_VERSION; }
@@ -306,6 +350,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_STAMP"))
+        h->opt_stamp = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_PARALLEL_FIT"))
         h->opt_pfit = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (!h->dry) {
@@ -352,10 +398,15 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
         if ((e2 = hipMemset(h->d_yv, 0, yv_b)) != hipSuccess) return bail("hipMemset", e2);
         for (int s = 0; s < kPlanSlots; s++) {
             // (a slot = the plans of a call followed by the compact channel lists of its launches: one upload)
-            if ((e2 = hipHostMalloc((void **)&h->h_plans[s], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
+            // (... behind the header the kernels find in front of the plans: psk_plan.h)
+            char *hb = nullptr, *db = nullptr;
+            if ((e2 = hipHostMalloc((void **)&hb, psk::kPlanHeaderBytes + (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
                 return bail("hipHostMalloc plans", e2);
-            if ((e2 = hipMalloc((void **)&h->d_plans[s], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
+            std::memset(hb, 0, psk::kPlanHeaderBytes);
+            h->h_plans[s] = reinterpret_cast<psk::ChanPlan *>(hb + psk::kPlanHeaderBytes);
+            if ((e2 = hipMalloc((void **)&db, psk::kPlanHeaderBytes + (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * n_channels)) != hipSuccess)
                 return bail("hipMalloc plans", e2);
+            h->d_plans[s] = reinterpret_cast<psk::ChanPlan *>(db + psk::kPlanHeaderBytes);
             if ((e2 = hipEventCreateWithFlags(&h->ev[s], hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e2);
             if ((e2 = hipEventCreateWithFlags(&h->ev_up[s], hipEventDisableTiming)) != hipSuccess)
@@ -379,8 +430,8 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
         if (h->stream)
             (void)hipStreamSynchronize(h->stream);
         for (int s = 0; s < kPlanSlots; s++) {
-            if (h->h_plans[s]) (void)hipHostFree(h->h_plans[s]);
-            if (h->d_plans[s]) (void)hipFree(h->d_plans[s]);
+            if (h->h_plans[s]) (void)hipHostFree(psk::plan_header(h->h_plans[s]));
+            if (h->d_plans[s]) (void)hipFree(psk::plan_header(h->d_plans[s]));
             if (h->ev[s]) (void)hipEventDestroy(h->ev[s]);
             if (h->ev_up[s]) (void)hipEventDestroy(h->ev_up[s]);
         }
@@ -431,6 +482,7 @@ psk_soft_status psk_soft_configure(psk_soft_handle_t *h, uint32_t ch0, uint32_t 
             return fail(PSK_SOFT_ERR_LIMIT, "psk_soft_configure: property exceeds the limits given at create "
                                             "(samplesPerBaud*numAvg, phaseAvg) or samplesPerBaud > 1024");
     }
+    ctl_touch(h);
     for (uint32_t i = 0; i < nch; i++) h->ctl[ch0 + i].configure(props[i]);
     return PSK_SOFT_OK;
 }
@@ -439,6 +491,7 @@ psk_soft_status psk_soft_query(const psk_soft_handle_t *h, uint32_t ch, psk_soft
 {
     if (!h || !props || ch >= h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_query: bad channel");
+    ctl_sync(h);
     *props = h->ctl[ch].props;
     return PSK_SOFT_OK;
 }
@@ -447,6 +500,7 @@ psk_soft_status psk_soft_fire_listener(psk_soft_handle_t *h, uint32_t ch, int wh
 {
     if (!h || ch >= h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_fire_listener: bad channel");
+    ctl_touch(h);
     switch (which) {
     case 0: h->ctl[ch].samplesPerBaudChanged(); break;
     case 1: h->ctl[ch].constelationSizeChanged(); break;
@@ -460,6 +514,7 @@ uint64_t psk_soft_output_capacity(const psk_soft_handle_t *h, uint32_t ch, uint6
 {
     if (!h || ch >= h->nch)
         return 0;
+    ctl_sync(h);
     uint64_t S = h->ctl[ch].props.samplesPerBaud ? h->ctl[ch].props.samplesPerBaud : 1;
     return (n_complex + S - 1) / S + 1;
 }
@@ -492,9 +547,125 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // plan on copies (ctl_next); commit only if every channel of the batch is accepted
     const bool dry = h->dry;
     const uint32_t extra_flags = h->opt_qpsk_sign_map ? (uint32_t)psk::PLAN_QPSK_SIGN_MAP : 0u;
+    const psk::Limits lim = h->lim;
+    // what a planned channel asks of the launches (`mult` channels with this very plan)
+    auto account = [&](const psk::ChanPlan &p, PlanSummary &r, uint32_t mult) {
+        r.any = true;
+        if (p.mode == psk::PLAN_FAST) {
+            if (p.n_out && (p.lf_flags & psk::PLAN_ANYFRONT)) {
+                r.any_emit = true;
+                r.cnt_any += mult;
+                const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
+                r.blocks_any += (uint64_t)nb * mult;
+                if (nb > r.max_blocks_any) r.max_blocks_any = nb;
+                if (p.lf_n > r.max_n_any) r.max_n_any = p.lf_n;
+                if (p.A > r.max_A_any) r.max_A_any = p.A;
+                if (p.S > r.max_S_any) r.max_S_any = p.S;
+            } else if (p.n_out) {
+                r.any_emit = true;
+                const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
+                r.need_SH[p.S][Hh] = true;
+                r.cnt_SH[p.S][Hh] += mult;
+                if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
+                if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
+                const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
+                r.blocks_SH[p.S][Hh] += (uint64_t)nb * mult;
+                if (nb > r.max_blocks_SH[p.S][Hh]) r.max_blocks_SH[p.S][Hh] = nb;
+            } else {
+                r.any_quiet = true;
+                r.cnt_quiet += mult;
+                if (p.lf_n > r.max_n_quiet) r.max_n_quiet = p.lf_n;
+            }
+        } else {
+            r.any_seq = true;
+            if (!lim.force_seq && p.lf_n <= lim.fast_fit_max &&
+                (p.n_out > psk::kResyncCount || (uint64_t)p.lf_count0 + p.n_out > psk::kResyncCount))
+                r.long_call = true;
+        }
+    };
+    uint32_t *const handed_over = dry ? nullptr : psk::plan_header(h->d_plans[slot]);  // (psk_plan.h)
+    auto misaligned = [&](const psk::ChanPlan &p) {
+        return !dry && ((p.n_in && !p.in) || ((uintptr_t)p.in & 7u) || ((uintptr_t)p.soft & 7u) || ((uintptr_t)p.bits & 3u) ||
+                        ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 3u));
+    };
+
+    // ---- the stamped path ----
+    // Channels that were configured alike and have been fed packets of the same length ever since hold IDENTICAL control state
+    // -- it depends on nothing else (psk_ctl.h) -- and a batch of equal packets then gets the same plan in every channel but for
+    // its five pointers.  Such a batch is planned ONCE: plan_call on channel ch0, the plan stamped into the other slots with
+    // the pointers patched, the result fields of outs[] copied, and the new control state kept in ONE copy (uni_ctl) that
+    // stands for the whole range until somebody looks at a single channel (ctl_sync).  What the loop below still does per
+    // channel is read the packet and the output descriptor (the equal-packets test) and write the plan: ~3 ns against ~14 ns.
+    // Anything unusual -- a refused call, a packet that differs, a buffer too small or misaligned -- leaves the stamped path for
+    // the ordinary one below, which plans every channel on its own and reports the error as it always did.
+    bool stamped = false;
+    psk::ChanCtl stamp_ctl;
+    PlanSummary res;
+    if (h->opt_stamp && !cont && nch >= 16u) {
+        bool uniform = false;
+        if (h->uni_hi > h->uni_lo && h->uni_lo == ch0 && h->uni_hi == ch0 + nch) {
+            uniform = true;
+        } else {
+            ctl_sync(h);
+            const bool known_mixed = h->mixed_ttl > 0 && h->mixed_lo == ch0 && h->mixed_hi == ch0 + nch;
+            if (known_mixed) {
+                h->mixed_ttl--;
+            } else {
+                uniform = true;
+                const psk::ChanCtl &c0 = h->ctl[ch0];
+                for (uint32_t i = 1; i < nch && uniform; i++) uniform = ctl_equal(c0, h->ctl[ch0 + i]);
+                if (uniform) {
+                    h->uni_lo = ch0, h->uni_hi = ch0 + nch, h->uni_lazy = false;
+                } else {
+                    h->mixed_lo = ch0, h->mixed_hi = ch0 + nch, h->mixed_ttl = 256;
+                }
+            }
+        }
+        if (uniform) {
+            stamp_ctl = h->uni_lazy ? h->uni_ctl : h->ctl[ch0];
+            psk::ChanPlan &p0 = plans[0];
+            const psk_soft_packet_t &k0 = pkts[0];
+            bool ok = stamp_ctl.props.samplesPerBaud <= kSeqMaxS &&
+                      psk::plan_call(stamp_ctl, lim, k0, outs[0], p0, false) == PSK_SOFT_OK && p0.mode != psk::PLAN_SKIP &&
+                      !misaligned(p0);
+            if (ok) {
+                p0.lf_flags |= extra_flags;
+                p0.handed_over = handed_over;
+                account(p0, res, nch);
+                ok = !res.long_call;
+            }
+            if (ok) {
+                const psk_soft_output_t o0 = outs[0];
+                const uint64_t n_out = p0.n_out;
+                uint32_t i = 1;
+                for (; i < nch; i++) {
+                    const psk_soft_packet_t &k = pkts[i];
+                    psk_soft_output_t &o = outs[i];
+                    if (k.n_floats != k0.n_floats || k.present != k0.present || k.sri_mode != k0.sri_mode || k.sriChanged != k0.sriChanged ||
+                        k.inputQueueFlushed != k0.inputQueueFlushed || std::memcmp(&k.sri_xdelta, &k0.sri_xdelta, sizeof(double)) != 0)
+                        break;
+                    if (n_out > o.cap_symbols && (o.soft || o.phase))
+                        break;
+                    psk::ChanPlan &p = plans[i];
+                    p = p0;
+                    p.in = k.data, p.soft = o.soft, p.bits = o.bits, p.phase = o.phase, p.sidx = o.sampleIndex;
+                    if (misaligned(p))
+                        break;
+                    o.ret = o0.ret, o.n_symbols = o0.n_symbols, o.n_bits = o0.n_bits, o.n_sampleIndex = o0.n_sampleIndex;
+                    o.sri_pushed = o0.sri_pushed, o.sri_soft_xdelta = o0.sri_soft_xdelta, o.sri_bits_xdelta = o0.sri_bits_xdelta;
+                    o.n_warn = o0.n_warn;
+                }
+                ok = i == nch;
+            }
+            stamped = ok;
+            if (!stamped)
+                res = PlanSummary();
+        }
+    }
+    if (!stamped)
+        ctl_touch(h);  // (the ordinary path writes the channels one by one)
     psk::ChanCtl *const next = h->ctl_next.data() + ch0;
     const psk::ChanCtl *const cur = h->ctl.data() + ch0;
-    const psk::Limits lim = h->lim;
     auto plan_range = [&](uint32_t lo, uint32_t hi, PlanSummary &r) {
         for (uint32_t i = lo; i < hi; i++) {
             next[i] = cur[i];
@@ -510,54 +681,23 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             }
             if (p.mode == psk::PLAN_SKIP)
                 continue;
-            if (!dry && ((p.n_in && !p.in) || ((uintptr_t)p.in & 7u) || ((uintptr_t)p.soft & 7u) ||
-                         ((uintptr_t)p.bits & 3u) || ((uintptr_t)p.phase & 3u) || ((uintptr_t)p.sidx & 3u))) {
+            if (misaligned(p)) {
                 r.st = PSK_SOFT_ERR_INVALID_ARG, r.bad = i, r.why = 2;
                 return;
             }
             p.lf_flags |= extra_flags;
+            p.handed_over = handed_over;
             if (cont && (cont[i] & 2u))
                 p.lf_flags |= psk::PLAN_NO_WRAP;  // (more pieces of this call follow)
-            r.any = true;
-            if (p.mode == psk::PLAN_FAST) {
-                if (p.n_out && (p.lf_flags & psk::PLAN_ANYFRONT)) {
-                    r.any_emit = true;
-                    r.cnt_any++;
-                    const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
-                    r.blocks_any += nb;
-                    if (nb > r.max_blocks_any) r.max_blocks_any = nb;
-                    if (p.lf_n > r.max_n_any) r.max_n_any = p.lf_n;
-                    if (p.A > r.max_A_any) r.max_A_any = p.A;
-                    if (p.S > r.max_S_any) r.max_S_any = p.S;
-                } else if (p.n_out) {
-                    r.any_emit = true;
-                    const int Hh = psk::fast_hist_blocks(p.A) + (p.lf_n > kDeepFit ? 8 : 0);
-                    r.need_SH[p.S][Hh] = true;
-                    r.cnt_SH[p.S][Hh]++;
-                    if (p.lf_n > r.max_n[p.S][Hh]) r.max_n[p.S][Hh] = p.lf_n;
-                    if (p.A > r.max_A[p.S][Hh]) r.max_A[p.S][Hh] = p.A;
-                    const uint32_t nb = (uint32_t)((p.n_out + 127u) / 128u);
-                    r.blocks_SH[p.S][Hh] += nb;
-                    if (nb > r.max_blocks_SH[p.S][Hh]) r.max_blocks_SH[p.S][Hh] = nb;
-                } else {
-                    r.any_quiet = true;
-                    r.cnt_quiet++;
-                    if (p.lf_n > r.max_n_quiet) r.max_n_quiet = p.lf_n;
-                }
-            } else {
-                r.any_seq = true;
-                if (!lim.force_seq && p.lf_n <= lim.fast_fit_max &&
-                    (p.n_out > psk::kResyncCount || (uint64_t)p.lf_count0 + p.n_out > psk::kResyncCount))
-                    r.long_call = true;
-            }
+            account(p, r, 1u);
         }
     };
-    // One thread: the pass is ~15 ns and ~0.5 KB of cache traffic per channel (60 us for 4096
+    // One thread: the ordinary pass is ~15 ns and ~0.5 KB of cache traffic per channel (60 us for 4096
     // channels).  Splitting it over a thread pool was measured and dropped: the workers' share is
     // done in 10-20 us, after which they sleep until the next call, and waking them costs more than
     // the whole pass (spinning instead would burn cores between packets).
-    PlanSummary res;
-    plan_range(0, nch, res);
+    if (!stamped)
+        plan_range(0, nch, res);
     if (res.st == PSK_SOFT_OK && res.long_call && !cont) {
         g_long_call = true;  // (nothing committed, nothing enqueued: the caller cuts the call into pieces)
         return PSK_SOFT_OK;
@@ -576,6 +716,13 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // before the first kernel launch leaves the channels untouched; one after it poisons the handle (device
     // state half advanced, nothing to roll it back with).
     auto commit = [&]() {
+        if (stamped) {  // (one copy stands for the range: see ctl_sync)
+            h->uni_ctl = stamp_ctl;
+            h->uni_mode = plans[0].mode;
+            h->uni_lo = ch0, h->uni_hi = ch0 + nch;
+            h->uni_lazy = true;
+            return;
+        }
         if (ch0 == 0 && nch == h->nch)
             h->ctl.swap(h->ctl_next);
         else
@@ -612,7 +759,9 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 run += res.cnt_SH[S][H];
             }
         uint32_t fill_SH[33][17] = {}, fill_quiet = 0, fill_any = 0;
-        for (uint32_t i = 0; i < nch; i++) {
+        if (stamped)  // (one class holds every channel, in order; the offsets of the others are equal to its end)
+            for (uint32_t i = 0; i < nch; i++) h_list[i] = i;
+        for (uint32_t i = 0; i < nch && !stamped; i++) {
             const psk::ChanPlan &p = plans[i];
             if (p.mode != psk::PLAN_FAST)
                 continue;
@@ -751,14 +900,20 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
             PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
     }
+    {
+        uint32_t *hdr = psk::plan_header(h->h_plans[slot]);
+        hdr[0] = 0u;                       // channels handed over: counted by the kernels
+        hdr[1] = res.any_seq ? 1u : 0u;    // channels planned for the reference-order kernel
+    }
+    const size_t up_bytes = psk::kPlanHeaderBytes + (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch;
     if (h->opt_up_stream) {
         // (the slot's previous user has finished -- waited for above --, nothing else reads or writes d_plans[slot])
-        PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
+        PSK_HIP(hipMemcpyAsync(psk::plan_header(h->d_plans[slot]), psk::plan_header(h->h_plans[slot]), up_bytes,
                                hipMemcpyHostToDevice, h->up_stream));
         PSK_HIP(hipEventRecord(h->ev_up[slot], h->up_stream));
         PSK_HIP(hipStreamWaitEvent(stream, h->ev_up[slot], 0));
     } else {
-        PSK_HIP(hipMemcpyAsync(h->d_plans[slot], h->h_plans[slot], (sizeof(psk::ChanPlan) + sizeof(uint32_t)) * nch,
+        PSK_HIP(hipMemcpyAsync(psk::plan_header(h->d_plans[slot]), psk::plan_header(h->h_plans[slot]), up_bytes,
                                hipMemcpyHostToDevice, stream));
     }
     // phase ring of a launch: a power of two >= phaseAvg + 128 for its channels, at least 512 floats (256 where
@@ -909,6 +1064,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     }
 
     // ---- pieces ----
+    ctl_sync(h);
     std::vector<psk_soft_packet_t> pk(pkts, pkts + nch);
     std::vector<psk_soft_output_t> ou(outs, outs + nch), total(outs, outs + nch);
     std::vector<uint64_t> left(nch);   // floats of the packet not yet handed over
@@ -968,6 +1124,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 h->poisoned = true;  // (pieces of the call have run: the channels are in the middle of it)
             return st;
         }
+        ctl_sync(h);
         for (uint32_t i = 0; i < nch; i++) {
             const psk_soft_output_t &o = ou[i];
             psk_soft_output_t &t = total[i];
@@ -996,6 +1153,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
         if (!more)
             break;
     }
+    ctl_sync(h);
     for (uint32_t i = 0; i < nch; i++) {
         outs[i] = total[i];
         h->last_mode[ch0 + i] = mode_of[i];
@@ -1078,6 +1236,7 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
         size_t in, soft, phase, bits, sidx;
     };
     std::vector<Need> need(nch);
+    ctl_sync(h);
     for (uint32_t i = 0; i < nch; i++) {
         if (pkts[i].present && pkts[i].n_floats / 2 > h->user.max_packet_complex)
             return fail(PSK_SOFT_ERR_LIMIT, "psk_soft_process_host: packet longer than max_packet_complex");
@@ -1268,6 +1427,7 @@ static psk_soft_status stats_range(psk_soft_handle_t *h, uint32_t ch0, uint32_t 
 {
     if (!h || !stats || (uint64_t)ch0 + nch > h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_get_stats: bad arguments");
+    ctl_sync(h);
     std::memset(stats, 0, sizeof *stats * (per_channel ? nch : 1));
     if (h->dry) {  // control plane only: which kernel the last call was PLANNED for, per channel
         for (uint32_t c = 0; c < nch; c++) {
@@ -1345,6 +1505,7 @@ psk_soft_status psk_soft_export_state(psk_soft_handle_t *h, uint32_t ch, void *d
 {
     if (!h || !dst || ch >= h->nch || cap < psk_soft_state_bytes(h))
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_export_state: bad arguments");
+    ctl_sync(h);
     uint8_t *p = (uint8_t *)dst;
     std::memset(p, 0, psk_soft_state_bytes(h));
     StateHeader hd = {kStateMagic, PSK_SOFT_ABI_VERSION, h->lim.ring_cap, h->lim.fit_cap, (uint32_t)sizeof(psk::ChanCtl),
@@ -1398,6 +1559,7 @@ psk_soft_status psk_soft_import_state(psk_soft_handle_t *h, uint32_t ch, const v
         p += sizeof(float2) * h->lim.ring_cap;
         PSK_HIP(hipMemcpy(h->d_yv + (size_t)ch * h->lim.fit_cap, p, sizeof(float) * h->lim.fit_cap, hipMemcpyHostToDevice));
     }
+    ctl_touch(h);
     h->ctl[ch] = c;  // (last: a failed copy above leaves the host mirror as it was)
     return PSK_SOFT_OK;
 }
@@ -1481,6 +1643,7 @@ psk_soft_status psk_soft_peek(const psk_soft_handle_t *h, uint32_t ch, uint64_t 
 {
     if (!h || ch >= h->nch)
         return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_peek: bad channel");
+    ctl_sync(h);
     if (ring_len) *ring_len = h->ctl[ch].ring_len;
     if (index) *index = h->ctl[ch].index;
     if (fit_len) *fit_len = h->ctl[ch].lf_len;

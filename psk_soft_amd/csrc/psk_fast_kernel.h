@@ -168,6 +168,10 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
         for (uint32_t i = 0; i < (hsh * (uint32_t)(PSK_STAGGER)) >> 8; i++) __builtin_amdgcn_s_sleep(16);
     }
 #endif
+    if constexpr (EXACT) {
+        if (plan_header(plans)[0] == 0u)
+            return;  // nothing was handed over in this call so far (psk_plan.h)
+    }
     // the launch covers the channels of the batch that this instantiation handles: list[workgroup] = index into the batch
     const uint32_t bi = list[blockIdx.x];
     const ChanPlan &p = plans[bi];
@@ -193,6 +197,9 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
 
     FastCarry cy;
     call_prologue(p, st, yv, fit_cap, yring, ymask, lane, cy);
+#ifdef PSK_DIAG_STAMP2  /* (diagnostic builds only: where a short call's time goes -- after the prologue, after the loop) */
+    const uint32_t diag_t1 = (uint32_t)wall_clock64();
+#endif
 
     // ---- the symbol loop ----
     if constexpr (SV != 0) {
@@ -201,6 +208,9 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
             pace_post(pace_key(), 0u, lane);  // (on every way out of the loop: nothing left, whoever takes this wave slot next)
     }
 
+#ifdef PSK_DIAG_STAMP2
+    const uint32_t diag_t2 = (uint32_t)wall_clock64();
+#endif
     // ---- exactness guard (quirk Q8): float-valued energies summed in double are exact, hence
     //      order-independent, only while 24 + exponent spread + log2(#terms) <= 53.  It matters only
     //      for calls in which an exact-timing pass met a best / runner-up pair closer than accumulated
@@ -220,8 +230,15 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
         cy.refuse = __any(cy.refuse);
     }
     if (cy.refuse) {
-        if (lane == 0)
+        if (lane == 0) {
             st->guard = 1u;  // nothing committed: psk_seq_kernel redoes this call from the old state
+            if (!EXACT)  // (a call the exact tier refuses was counted when it was handed to it)
+#ifdef PSK_HANDOVER_VIA_ARG  /* (A/B builds: the variant measured 10 % slower on one box) */
+                atomicAdd(plan_header(plans), 1u);
+#else
+                atomicAdd(p.handed_over, 1u);
+#endif
+        }
         return;
     }
 
@@ -233,6 +250,10 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
         st->emax_hint = __uint_as_float((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20));
 #else
         st->stat_pfit = diag_t0;
+#endif
+#ifdef PSK_DIAG_STAMP2
+        st->emax_hint = __uint_as_float(diag_t1);
+        st->stat_chain = diag_t2;
 #endif
         st->pad_state = (uint32_t)wall_clock64();
     }

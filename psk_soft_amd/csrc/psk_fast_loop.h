@@ -1174,6 +1174,12 @@ PSK_DEV void output_stage(const ChanPlan &p, int c, int i0, const bool (&valid)[
 #define PSK_PACE 1
 #endif
 #define PSK_PACE_ON(FRONT_, EXACT_) (PSK_PACE != 0 && !(FRONT_) && !(EXACT_))
+#ifndef PSK_PACE_SHORT
+#define PSK_PACE_SHORT 12
+#endif
+#ifndef PSK_PACE_SHORT_MODE
+#define PSK_PACE_SHORT_MODE 2
+#endif
 #ifndef PSK_PACE_EVERY
 #define PSK_PACE_EVERY 4  /* blocks between two looks at the table (a power of two): every block 2.57 ms, every second 2.39, every fourth 2.37, never 2.44 (headline, one box) */
 #endif
@@ -1367,6 +1373,9 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if (c_begin < n_blocks)
             load_block<S>(X, (long long)c_begin, A, 0, tau_last, lane, xnext);
     }
+#if PSK_PACE_SHORT_MODE == 2
+    const int pace_mask = n_blocks <= PSK_PACE_SHORT ? 0 : PSK_PACE_EVERY - 1;
+#endif
     for (int c = c_begin; c < n_blocks; c++) {
         // Without pacing: the memory-facing half of the block (loads, their use, the LDS ring) runs at raised wave
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
@@ -1375,7 +1384,16 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if constexpr (!PSK_PACE_ON(FRONT, EXACT))
             __builtin_amdgcn_s_setprio(3);
         uint32_t pace_row = 0u;
-        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && (c & (PSK_PACE_EVERY - 1)) == 0;  // (wave-uniform)
+        // (wave-uniform; a call of a few blocks looks every block: it is over before the fourth)
+#if PSK_PACE_SHORT_MODE == 1
+        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && ((c & (PSK_PACE_EVERY - 1)) == 0 || n_blocks <= PSK_PACE_SHORT);
+#elif PSK_PACE_SHORT_MODE == 3
+        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && ((c & (PSK_PACE_EVERY - 1)) == 0 || c < PSK_PACE_SHORT);
+#elif PSK_PACE_SHORT_MODE == 2
+        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && (c & pace_mask) == 0;
+#else
+        const bool pace_now = PSK_PACE_ON(FRONT, EXACT) && (c & (PSK_PACE_EVERY - 1)) == 0;
+#endif
         if (pace_now)
             pace_row = pace_fetch(pace, lane);  // (in front of the block's loads: it is back before they are)
         float2 xn[kR][S];

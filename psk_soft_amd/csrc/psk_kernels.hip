@@ -164,6 +164,11 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
     __shared__ float2 chunk[kSeqChunk];
     __shared__ uint64_t sh_head;
     const int lane = threadIdx.x & 63;
+    {
+        const uint32_t *hdr = plan_header(plans);
+        if (hdr[0] == 0u && hdr[1] == 0u)
+            return;  // no channel planned for this kernel, none handed over (psk_plan.h)
+    }
     const ChanPlan &p = plans[blockIdx.x];
     const uint32_t ch = ch0 + blockIdx.x;
     ChanState *st = &states[ch];

@@ -78,7 +78,26 @@ struct ChanPlan {
     uint32_t tile_base;    // index of the channel's first TileInfo
     uint32_t tile_pad;
     uint64_t tile_off;     // offset of its first symbol in the raw-phase / picked-sample / estimate arrays
+    // word 0 of the header in front of the call's plans in device memory (plan_header() below): the kernel that hands this
+    // channel's call over counts it there.  (In every plan, although every kernel could find the header from its `plans`
+    // argument: holding that argument across the symbol loop for the one refusal in thousands of calls cost the headline
+    // instantiation eleven more spilled scalar registers and 10 % of its speed.)
+    uint32_t *handed_over;
 };
+
+// The plans of a call sit behind a small header in device memory (uploaded with them, one copy): word 0 counts the channels
+// of the call that a kernel has handed over so far (ChanState::guard = 1) -- zero at upload, so the exact-timing and the
+// reference-order launches of a call in which nothing was handed over end at their first instruction instead of reading plan
+// and state of every channel to find that out (4.8 + 4.2 us of a 4096-channel call) --, word 1 says whether the host planned any
+// channel for the reference-order kernel.  The kernels find the header in front of `plans`.
+constexpr unsigned kPlanHeaderBytes = 128u;
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline uint32_t *plan_header(const ChanPlan *plans)
+{
+    return reinterpret_cast<uint32_t *>(const_cast<char *>(reinterpret_cast<const char *>(plans)) - kPlanHeaderBytes);
+}
 
 // What one tile of the time-tiled front kernel reports (psk_tile_kernel.h): the fit kernel, one wave per channel,
 // folds the tiles of its channel together and decides for the whole call.

@@ -511,8 +511,10 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     if (lane == 0)
         st->emax_hint = emax;  // (not part of the reference's state: kept whether or not the call stays here)
     if (refuse) {
-        if (lane == 0)
+        if (lane == 0) {
             st->guard = 1u;
+            atomicAdd(p.handed_over, 1u);
+        }
         return;
     }
     if ((p.lf_flags & PLAN_PFIT) && sc.chan[bi].fail == 0u) {
@@ -559,8 +561,10 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
         float est[kR];
         fit_stage<false>(c, lane, n, xd, den_s, xavg_s, fk, valid, raw, nvalid, lane_last, r_last, yring, ymask, cy, est);
         if (__any(cy.refuse)) {
-            if (lane == 0)
+            if (lane == 0) {
                 st->guard = 1u;
+                atomicAdd(p.handed_over, 1u);
+            }
             return;
         }
         *reinterpret_cast<float2 *>(est_row + i0) = make_float2(est[0], est[1]);  // (rows padded to whole blocks)

@@ -124,6 +124,67 @@ def test_large_batch_equals_channel_by_channel():
     one.close()
 
 
+def test_stamped_batch_equals_channel_by_channel():
+    """Channels configured alike and fed equal packets are planned ONCE and the plan stamped into the other slots
+    (psk_capi.cpp, "the stamped path"), their control state kept in one copy until somebody looks at a single channel.
+    Results, committed state, statistics and refusals must be those of a one-channel-at-a-time pass -- through every way in
+    and out of the stamped path: a packet that differs, a channel reconfigured and set back, a partial range, a peek in
+    between, a refused call."""
+    rng = random.Random(4242)
+    n_ch = 600
+    for S, A, n, M in ((8, 100, 50, 4), (10, 400, 200, 8), (1, 0, 50, 2), (3, 25, 1, 3)):
+        big = pl.Handle(n_ch, device=pl.DEVICE_NONE, max_window_samples=1 << 14, max_phase_avg=512)
+        one = pl.Handle(n_ch, device=pl.DEVICE_NONE, max_window_samples=1 << 14, max_phase_avg=512)
+        prop = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n)
+        big.configure_all(**prop)
+        one.configure_all(**prop)
+
+        def both(ch0, pk, ctx):
+            got = big.plan_only(ch0, pk)
+            ref = [one.plan_only(ch0 + c, [pk[c]])[0] for c in range(len(pk))]
+            assert got == ref, ctx
+            return got
+
+        for call in range(14):
+            nf = 2 * rng.choice([0, 3, 64, 777, 4096, 20000]) + (rng.random() < 0.1)
+            base = dict(n_floats=nf, xdelta=rng.choice([0.01, 0.01, 0.5]), sriChanged=(call == 0 or rng.random() < 0.1),
+                        inputQueueFlushed=(rng.random() < 0.1), mode=(0 if rng.random() < 0.05 and call != 11 else 1))
+            pk = [dict(base) for _ in range(n_ch)]
+            ctx = (S, A, call)
+            if call == 4:  # one packet differs: the whole batch is planned channel by channel
+                pk[311]["n_floats"] = nf + 16
+            if call == 6:  # a channel reconfigured and set back: its listeners have fired, it is no longer like the others
+                for hh in (big, one):
+                    hh.configure(17, [dict(phaseAvg=7)])
+                    hh.configure(17, [dict(phaseAvg=n)])
+            if call == 8:  # a missing packet
+                pk[5] = None
+            if call == 10:  # a partial range, twice, then the whole handle again
+                both(100, pk[100:400], ctx)
+                both(100, pk[100:400], ctx)
+            if call == 11:  # a refused call leaves everything as it was
+                for hh in (big, one):
+                    hh.configure(333, [dict(phaseAvg=0)])
+                before = [big.peek(c) for c in (0, 332, 333, 334, n_ch - 1)]
+                with pytest.raises(pl.PskSoftError) as ei:
+                    big.plan_only(0, pk)
+                assert "channel 333 " in str(ei.value)
+                assert [big.peek(c) for c in (0, 332, 333, 334, n_ch - 1)] == before
+                for hh in (big, one):
+                    hh.configure(333, [dict(phaseAvg=n)])
+            both(0, pk, ctx)
+            if call % 3 == 2:  # (a look at single channels brings the per-channel mirror up to date)
+                assert [big.peek(c) for c in range(0, n_ch, 37)] == [one.peek(c) for c in range(0, n_ch, 37)], ctx
+            if call % 5 == 4:
+                sb, so = big.stats(), one.stats()
+                assert (sb["channels_fast"], sb["channels_sequential"]) == (so["channels_fast"], so["channels_sequential"]), ctx
+        assert [big.peek(c) for c in range(n_ch)] == [one.peek(c) for c in range(n_ch)]
+        as_tuple = lambda q: tuple(getattr(q, k) for k, _ in q._fields_)
+        assert [as_tuple(big.query(c)) for c in range(0, n_ch, 50)] == [as_tuple(one.query(c)) for c in range(0, n_ch, 50)]
+        big.close()
+        one.close()
+
+
 def test_which_kernel_a_configuration_is_planned_for():
     """The wave-scan kernels have instantiations for samplesPerBaud 2 .. 32, numAvg <= 1024 (<= 512 for samplesPerBaud
     > 16); window classes beyond that are planned for the time-tiled kernels behind their run-time front stage

@@ -72,4 +72,4 @@ wall = (time.perf_counter() - t0) / reps * 1e6
 print("issue     : %7.1f us per call (CPU, no sync)" % issue)
 print("steady    : %7.1f us per call (wall, %d calls back to back)" % (wall, reps))
 print("device    : %7.1f us per call (HIP events)" % (e0.elapsed_time(e1) / reps * 1e3))
-print("stream rate: %.1f Gsamples/s, %.1f %% of the 8 TB/s read roofline" % (C * N / wall / 1e3, 8.0 * C * N / wall / 1e6 / 8e6 * 100))
+print("stream rate: %.1f Gsamples/s, %.1f %% of the 8 TB/s read roofline" % (C * N / wall / 1e3, 8.0 * C * N / (wall * 1e-6) / 8e12 * 100))
