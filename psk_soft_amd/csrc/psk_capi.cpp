@@ -228,12 +228,18 @@ struct psk_soft_handle {
     std::vector<psk::ChanPlan> plans_dry;   // plans of a control-plane-only handle (no pinned slots)
     std::vector<uint32_t> last_mode;  // PlanMode of the last call, per channel (statistics)
     // Uniform run of the control plane (the stamped path of process_round): the channels [uni_lo, uni_hi) are known to hold
-    // IDENTICAL control state.  While uni_lazy is set that state lives in uni_ctl / uni_mode alone and ctl[] / last_mode[] of
+    // IDENTICAL control state.  While `lazy` is set that state lives in the run's ctl / mode alone and ctl[] / last_mode[] of
     // the range are stale: every reader goes through ctl_sync() first, every writer through ctl_touch().
-    uint32_t uni_lo = 0, uni_hi = 0;
-    bool uni_lazy = false;
-    psk::ChanCtl uni_ctl;
-    uint32_t uni_mode = psk::PLAN_SKIP;
+    // A few such runs are kept side by side (disjoint): a caller that feeds a handle in two or four slices on as many streams --
+    // so that the tail of one slice's launch overlaps the body of the next's -- keeps all of them stamped.
+    struct UniRun {
+        uint32_t lo = 0, hi = 0;
+        bool lazy = false;
+        psk::ChanCtl ctl;
+        uint32_t mode = psk::PLAN_SKIP;
+    };
+    static constexpr int kUniRuns = 8;
+    UniRun uni[kUniRuns];
     uint32_t mixed_lo = 0, mixed_hi = 0;  // a range that was compared and found mixed ...
     int mixed_ttl = 0;                    // ... is not compared again for this many calls (or until something is configured)
     int opt_stamp = 1;                    // PSK_SOFT_STAMP=0 (environment): every channel planned on its own (A/B runs, tests)
@@ -282,25 +288,49 @@ struct psk_soft_handle {
 };
 
 namespace {
-// the per-channel mirror brought up to date (see psk_soft_handle::uni_lazy)
+// the per-channel mirror of one run brought up to date (see psk_soft_handle::UniRun)
+void run_sync(psk_soft_handle *h, psk_soft_handle::UniRun &r)
+{
+    if (!r.lazy)
+        return;
+    for (uint32_t i = r.lo; i < r.hi; i++) {
+        h->ctl[i] = r.ctl;
+        h->last_mode[i] = r.mode;
+    }
+    r.lazy = false;
+}
+// ... of the whole handle
 void ctl_sync(const psk_soft_handle *hc)
 {
     psk_soft_handle *h = const_cast<psk_soft_handle *>(hc);
-    if (!h->uni_lazy)
-        return;
-    for (uint32_t i = h->uni_lo; i < h->uni_hi; i++) {
-        h->ctl[i] = h->uni_ctl;
-        h->last_mode[i] = h->uni_mode;
-    }
-    h->uni_lazy = false;
+    for (auto &r : h->uni) run_sync(h, r);
 }
 // ... and about to be changed channel by channel: nothing is known to be uniform any more
 void ctl_touch(psk_soft_handle *h)
 {
-    ctl_sync(h);
-    h->uni_lo = h->uni_hi = 0;
+    for (auto &r : h->uni) {
+        run_sync(h, r);
+        r.lo = r.hi = 0;
+    }
     h->mixed_lo = h->mixed_hi = 0;
     h->mixed_ttl = 0;
+}
+// ... of the channels [lo, hi), which are about to be planned one by one: the runs that overlap them end
+void ctl_touch_range(psk_soft_handle *h, uint32_t lo, uint32_t hi)
+{
+    for (auto &r : h->uni)
+        if (r.hi > r.lo && r.lo < hi && lo < r.hi) {
+            run_sync(h, r);
+            r.lo = r.hi = 0;
+        }
+}
+// the run that is exactly [lo, hi), or none
+psk_soft_handle::UniRun *run_find(psk_soft_handle *h, uint32_t lo, uint32_t hi)
+{
+    for (auto &r : h->uni)
+        if (r.hi > r.lo && r.lo == lo && r.hi == hi)
+            return &r;
+    return nullptr;
 }
 bool ctl_equal(const psk::ChanCtl &a, const psk::ChanCtl &b)
 {
@@ -600,13 +630,15 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // the ordinary one below, which plans every channel on its own and reports the error as it always did.
     bool stamped = false;
     psk::ChanCtl stamp_ctl;
+    psk_soft_handle::UniRun *run = nullptr;
     PlanSummary res;
     if (h->opt_stamp && !cont && nch >= 16u) {
         bool uniform = false;
-        if (h->uni_hi > h->uni_lo && h->uni_lo == ch0 && h->uni_hi == ch0 + nch) {
+        run = run_find(h, ch0, ch0 + nch);
+        if (run) {
             uniform = true;
         } else {
-            ctl_sync(h);
+            ctl_touch_range(h, ch0, ch0 + nch);  // (runs that overlap the range without being it)
             const bool known_mixed = h->mixed_ttl > 0 && h->mixed_lo == ch0 && h->mixed_hi == ch0 + nch;
             if (known_mixed) {
                 h->mixed_ttl--;
@@ -615,14 +647,23 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 const psk::ChanCtl &c0 = h->ctl[ch0];
                 for (uint32_t i = 1; i < nch && uniform; i++) uniform = ctl_equal(c0, h->ctl[ch0 + i]);
                 if (uniform) {
-                    h->uni_lo = ch0, h->uni_hi = ch0 + nch, h->uni_lazy = false;
+                    for (auto &r : h->uni)
+                        if (r.hi == r.lo) {
+                            run = &r;
+                            break;
+                        }
+                    if (!run) {  // (every slot taken: the first one makes room)
+                        run = &h->uni[0];
+                        run_sync(h, *run);
+                    }
+                    run->lo = ch0, run->hi = ch0 + nch, run->lazy = false;
                 } else {
                     h->mixed_lo = ch0, h->mixed_hi = ch0 + nch, h->mixed_ttl = 256;
                 }
             }
         }
         if (uniform) {
-            stamp_ctl = h->uni_lazy ? h->uni_ctl : h->ctl[ch0];
+            stamp_ctl = run->lazy ? run->ctl : h->ctl[ch0];
             psk::ChanPlan &p0 = plans[0];
             const psk_soft_packet_t &k0 = pkts[0];
             bool ok = stamp_ctl.props.samplesPerBaud <= kSeqMaxS &&
@@ -663,7 +704,7 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         }
     }
     if (!stamped)
-        ctl_touch(h);  // (the ordinary path writes the channels one by one)
+        ctl_touch_range(h, ch0, ch0 + nch);  // (the ordinary path writes the channels one by one)
     psk::ChanCtl *const next = h->ctl_next.data() + ch0;
     const psk::ChanCtl *const cur = h->ctl.data() + ch0;
     auto plan_range = [&](uint32_t lo, uint32_t hi, PlanSummary &r) {
@@ -717,10 +758,9 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // state half advanced, nothing to roll it back with).
     auto commit = [&]() {
         if (stamped) {  // (one copy stands for the range: see ctl_sync)
-            h->uni_ctl = stamp_ctl;
-            h->uni_mode = plans[0].mode;
-            h->uni_lo = ch0, h->uni_hi = ch0 + nch;
-            h->uni_lazy = true;
+            run->ctl = stamp_ctl;
+            run->mode = plans[0].mode;
+            run->lazy = true;
             return;
         }
         if (ch0 == 0 && nch == h->nch)

@@ -172,6 +172,15 @@ def test_stamped_batch_equals_channel_by_channel():
                 assert [big.peek(c) for c in (0, 332, 333, 334, n_ch - 1)] == before
                 for hh in (big, one):
                     hh.configure(333, [dict(phaseAvg=n)])
+            if call in (12, 13):  # the handle fed in three slices (each keeps its own stamped run), then whole again
+                both(0, pk[:200], ctx)
+                both(200, pk[200:450], ctx)
+                both(450, pk[450:], ctx)
+                both(0, pk[:200], ctx)
+                both(450, pk[450:], ctx)
+                both(200, pk[200:450], ctx)
+                if call == 13:
+                    both(100, pk[100:300], ctx)  # (a slice across two runs)
             both(0, pk, ctx)
             if call % 3 == 2:  # (a look at single channels brings the per-channel mirror up to date)
                 assert [big.peek(c) for c in range(0, n_ch, 37)] == [one.peek(c) for c in range(0, n_ch, 37)], ctx

@@ -7,6 +7,7 @@ Prints, per call of `channels` channels x `nsamp` complex samples (QPSK, 8 sampl
   steady         -- wall time per call over a long run of back-to-back calls (= max(issue, device))
   device         -- HIP-event time around the calls on their stream
 """
+import ctypes
 import os
 import sys
 import time
@@ -72,4 +73,27 @@ wall = (time.perf_counter() - t0) / reps * 1e6
 print("issue     : %7.1f us per call (CPU, no sync)" % issue)
 print("steady    : %7.1f us per call (wall, %d calls back to back)" % (wall, reps))
 print("device    : %7.1f us per call (HIP events)" % (e0.elapsed_time(e1) / reps * 1e3))
+# the same batch fed in G slices on G streams: the tail of one slice's launch (its slowest waves) overlaps the body of the next's
+for G in (2, 4):
+    streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+    step = C // G
+    views = [((pl.Packet * step).from_address(ctypes.addressof(pk) + g * step * ctypes.sizeof(pl.Packet)),
+              (pl.Output * step).from_address(ctypes.addressof(out) + g * step * ctypes.sizeof(pl.Output))) for g in range(G)]
+
+    def run_sliced(reps):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for g in range(G):
+                h.process_device(g * step, views[g][0], views[g][1], stream=streams[g].cuda_stream)
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    torch.cuda.synchronize()
+    run_sliced(200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    issue_g = run_sliced(reps)
+    torch.cuda.synchronize()
+    wall_g = (time.perf_counter() - t0) / reps * 1e6
+    print("%d slices on %d streams: issue %7.1f us, steady %7.1f us per %d-channel batch (%.1f %% of the 8 TB/s read roofline)"
+          % (G, G, issue_g, wall_g, C, 8.0 * C * N / (wall_g * 1e-6) / 8e12 * 100))
 print("stream rate: %.1f Gsamples/s, %.1f %% of the 8 TB/s read roofline" % (C * N / wall / 1e3, 8.0 * C * N / (wall * 1e-6) / 8e12 * 100))
