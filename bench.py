@@ -298,16 +298,30 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
         out[c].cap_symbols = cap
     stream = torch.cuda.Stream(device=dev)
     stream.wait_stream(torch.cuda.current_stream(dev))  # (the stimulus is generated on torch's current stream)
-    for _ in range(warmup):
-        h.process_device(0, pk, out, stream=stream.cuda_stream)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(steps):
-        h.process_device(0, pk, out, stream=stream.cuda_stream)
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / steps
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            h.process_device(0, pk, out, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n_steps):
+            h.process_device(0, pk, out, stream=stream.cuda_stream)
+        h.join(stream.cuda_stream)  # (deferred join: the stream waits for the side streams of all the steps; else a no-op)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n_steps
+
+    joined_ms = None
+    if mixed:
+        # the mixed batch twice: every call joined into the caller's stream (the default), then with the join deferred to the
+        # end of the timed steps (PSK_SOFT_OPT_DEFERRED_JOIN: the classes run ahead into the following calls on their own streams)
+        joined_ms = timed(warmup, steps)
+        h.set_option(pl.Handle.OPT_DEFERRED_JOIN, 1)
+        ms = timed(5, steps)
+        replay = warmup + steps + 5 + steps  # (calls the oracle has to replay below)
+    else:
+        ms = timed(warmup, steps)
+        replay = warmup + steps
     st = h.stats()
     n_out = int(out[0].n_symbols)
     res = {"workload": name, "channels": C, "samples_per_channel_per_step": N, "ms_per_step": ms,
@@ -315,6 +329,11 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
            "steps": steps, "warmup": warmup,
            "kernel_stats": {k: st[k] for k in ("channels_fast", "channels_exact_timing", "channels_sequential", "unwrap_blocks",
                                                "unwrap_extra_passes", "timing_exact_blocks", "fit_chain_blocks")}}
+    if joined_ms is not None:
+        res["join"] = ("deferred (PSK_SOFT_OPT_DEFERRED_JOIN): the window classes end their calls on streams of their own and are "
+                       "joined once, behind the last timed step, inside the timed region")
+        res["ms_per_step_every_call_joined"] = joined_ms
+        res["frac_of_hbm_read_roofline_every_call_joined"] = 8.0 * C * N / (joined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if check:
         import numpy as np
 
@@ -327,7 +346,7 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
                 setattr(comp, kk, vv)
             x = iq[c].cpu().numpy()
             r = None
-            for _ in range(warmup + steps):
+            for _ in range(replay):
                 r = comp.service(x, 0.01, sriChanged=False)
             b = {2: 1, 4: 2, 8: 3}.get(props[c]["constelationSize"], 0)
             for nm, g, w, dt in (("soft", soft[c, : 2 * n_out], r.soft, np.uint32), ("phase", phase[c, :n_out], r.phase, np.uint32),
@@ -340,7 +359,7 @@ def sub_bench(pl, torch, dev, dev_index, name, C=4096, N=1 << 18, M=4, S=8, numA
                     sys.stderr.write("%s: channel %d, %s: %d of %d values differ (sizes %d / %d), first at %s\n"
                                      % (name[:40], c, nm, d.size, wa.size, ga.size, wa.size, d[:4].tolist()))
                 same = same and ok
-        res["check"] = {"channels": [0, C - 1], "calls_replayed": warmup + steps, "all_four_streams_bit_identical": bool(same)}
+        res["check"] = {"channels": [0, C - 1], "calls_replayed": replay, "all_four_streams_bit_identical": bool(same)}
         assert same, "%s: the HIP path differs from the oracle" % name
     h.close()
     del iq, soft, phase, sidx, bits

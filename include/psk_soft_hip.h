@@ -169,6 +169,11 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
 psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch,
                                       const psk_soft_packet_t *pkts, psk_soft_output_t *outs);
 psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h);
+
+/* PSK_SOFT_OPT_DEFERRED_JOIN: make `stream` (a hipStream_t; NULL = the handle's own) wait for everything the calls made so
+ * far have put on the handle's side streams -- the point in stream order behind which their results may be used.  A no-op
+ * without pending deferred calls.  (There is no counterpart in the reference: its serviceFunction() is synchronous.) */
+psk_soft_status psk_soft_join(psk_soft_handle_t *h, void *stream);
 psk_soft_status psk_soft_get_stats(psk_soft_handle_t *h, psk_soft_stats_t *stats);
 /* the same, one record per channel of [ch0, ch0+nch) (stats[nch]) */
 psk_soft_status psk_soft_get_channel_stats(psk_soft_handle_t *h, uint32_t ch0, uint32_t nch, psk_soft_stats_t *stats);
@@ -195,7 +200,16 @@ enum {
      * position by position, a second round on corrected unwrap counts enqueued for a while after a call whose first
      * guess failed; 2 = the second round always enqueued; 0 = walked block by block, one wave per channel.  No effect on
      * results.  Environment: PSK_SOFT_PARALLEL_FIT. */
-    PSK_SOFT_OPT_PARALLEL_FIT = 4
+    PSK_SOFT_OPT_PARALLEL_FIT = 4,
+    /* 1 = deferred join (default 0).  A batch that mixes window classes runs its classes on side streams of the handle.  By
+     * default every call ends with the caller's stream waiting for them (results in stream order, like everything else).
+     * With this option it does not: every class ends its calls on its own stream and the next call's launches of that class
+     * queue behind them there, so a class with short launches runs ahead into the following calls while another is still
+     * busy (configs[4] of the benchmark: 3.4 -> 2.8 ms per step).  The caller's stream -- or any stream -- sees the results of all
+     * calls made so far after psk_soft_join(); psk_soft_synchronize() waits for them on the host.  Results are unchanged.
+     * A call whose channels would not all stay on the stream they were on (a property or packet pattern that moves a channel
+     * to another window class) joins everything first, by itself. */
+    PSK_SOFT_OPT_DEFERRED_JOIN = 5
 };
 psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value);
 

@@ -28,7 +28,7 @@ namespace psk {
 hipError_t launch_fast(int S, int H, int exact, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, uint32_t r_len,
                        hipStream_t stream);
-hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+hipError_t launch_seq(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream);
 hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipStream_t stream);
 // time-tiled kernels (psk_tile.hip)
@@ -262,6 +262,19 @@ struct psk_soft_handle {
     hipStream_t aux[kAuxStreams] = {};     // created on first use
     hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {};
     int opt_fork = 1;                       // PSK_SOFT_OPT_CONCURRENT_CLASSES
+    // PSK_SOFT_OPT_DEFERRED_JOIN: the side streams of a batch that mixes window classes are NOT joined into the caller's stream at
+    // the end of the call -- every class ends its calls on its own stream (exact tier and reference-order hand-over included) and
+    // the next call's launches of the class queue behind them there, so that a short class runs ahead into the next calls while a
+    // long one is still busy.  The caller's stream sees the results after psk_soft_join() / psk_soft_synchronize().  Safe as long
+    // as every channel keeps going to the same stream: the channel -> stream assignment of a call is hashed (deferred_sig), and
+    // a call whose assignment differs from the pending one joins everything first.
+    int opt_deferred = 0;
+    bool deferred_pending = false;
+    uint64_t deferred_sig = 0;
+    uint32_t deferred_ch0 = 0, deferred_nch = 0;
+    hipStream_t deferred_stream = nullptr;
+    hipEvent_t slot_aux_ev[kPlanSlots][kAuxStreams] = {};  // end of a deferred call on each side stream (a plan slot is reused after them too)
+    bool slot_aux_used[kPlanSlots][kAuxStreams] = {};
     // what the call that last used each plan slot worked on, and on which stream (its end is the slot's event)
     hipStream_t slot_stream[kPlanSlots] = {};
     uint32_t slot_ch0[kPlanSlots] = {}, slot_nch[kPlanSlots] = {};
@@ -331,6 +344,22 @@ psk_soft_handle::UniRun *run_find(psk_soft_handle *h, uint32_t lo, uint32_t hi)
         if (r.hi > r.lo && r.lo == lo && r.hi == hi)
             return &r;
     return nullptr;
+}
+// PSK_SOFT_OPT_DEFERRED_JOIN: `stream` waits for everything the side streams still carry
+hipError_t deferred_join(psk_soft_handle *h, hipStream_t stream)
+{
+    if (!h->deferred_pending)
+        return hipSuccess;
+    for (int a = 0; a < kAuxStreams; a++) {
+        if (!h->aux[a])
+            continue;
+        if (const hipError_t e = hipEventRecord(h->aux_join[a], h->aux[a]))
+            return e;
+        if (const hipError_t e = hipStreamWaitEvent(stream, h->aux_join[a], 0))
+            return e;
+    }
+    h->deferred_pending = false;
+    return hipSuccess;
 }
 bool ctl_equal(const psk::ChanCtl &a, const psk::ChanCtl &b)
 {
@@ -491,6 +520,9 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
             if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
         }
         if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
+        for (auto &row : h->slot_aux_ev)
+            for (hipEvent_t &e : row)
+                if (e) (void)hipEventDestroy(e);
         if (h->up_stream) {
             (void)hipStreamSynchronize(h->up_stream);
             (void)hipStreamDestroy(h->up_stream);
@@ -572,6 +604,11 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         PSK_HIP(hipSetDevice(h->device));
         if (h->ev_used[slot])
             PSK_HIP(hipEventSynchronize(h->ev[slot]));
+        for (int a = 0; a < kAuxStreams; a++)
+            if (h->slot_aux_used[slot][a]) {  // (a deferred call's classes end on the side streams)
+                PSK_HIP(hipEventSynchronize(h->slot_aux_ev[slot][a]));
+                h->slot_aux_used[slot][a] = false;
+            }
         plans = h->h_plans[slot];
     }
     // plan on copies (ctl_next); commit only if every channel of the batch is accepted
@@ -783,8 +820,12 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     // whose channel range overlaps its own (same stream: the stream orders them; older calls than the plan slots
     // remember have completed -- a slot is only reused after its event).
     for (int k = 0; k < kPlanSlots; k++)
-        if (k != slot && h->ev_used[k] && h->slot_stream[k] != stream && h->slot_ch0[k] < ch0 + nch && ch0 < h->slot_ch0[k] + h->slot_nch[k])
+        if (k != slot && h->ev_used[k] && h->slot_stream[k] != stream && h->slot_ch0[k] < ch0 + nch && ch0 < h->slot_ch0[k] + h->slot_nch[k]) {
             PSK_HIP(hipStreamWaitEvent(stream, h->ev[k], 0));
+            for (int a = 0; a < kAuxStreams; a++)
+                if (h->slot_aux_used[k][a])
+                    PSK_HIP(hipStreamWaitEvent(stream, h->slot_aux_ev[k][a], 0));
+        }
     // compact lists, one per launch, behind the plans: first the channels that emit nothing, then every (S, H)
     // class in launch order
     uint32_t *const h_list = reinterpret_cast<uint32_t *>(h->h_plans[slot] + nch);
@@ -940,6 +981,36 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
             PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
     }
+    // window classes of the call in launch order (deepest history first); class 0 stays on the caller's stream, the others take
+    // the side streams in turn
+    struct Cls {
+        int S, H;
+    };
+    Cls cls[33 * 8];
+    int n_cls = 0;
+    for (int k = 7; k >= 0; k--)
+        for (int S : kFastS)
+            if (need_SH[S][kClassH[k]])
+                cls[n_cls++] = Cls{S, kClassH[k]};
+    const bool fork = n_cls > 1 && h->opt_fork;
+    // deferred join (see psk_soft_handle::opt_deferred): only calls whose every channel runs on wave-scan launches
+    bool deferred = fork && h->opt_deferred && !cont && !tile_syms && !res.cnt_any && !res.any_seq;
+    uint64_t sig = 1469598103934665603ull;
+    if (deferred) {
+        auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+        mix(ch0), mix(nch), mix((uint64_t)(uintptr_t)stream), mix((uint64_t)n_cls), mix(res.cnt_quiet);
+        for (int i = 0; i < n_cls; i++) mix(((uint64_t)cls[i].S << 40) | ((uint64_t)cls[i].H << 32) | res.cnt_SH[cls[i].S][cls[i].H]);
+        for (uint32_t i = 0; i < nch; i++) mix(h_list[i]);  // (no planned SKIP / SEQ channels here: the lists hold all nch)
+        uint32_t listed = res.cnt_quiet;
+        for (int i = 0; i < n_cls; i++) listed += res.cnt_SH[cls[i].S][cls[i].H];
+        if (listed != nch)  // (channels without a packet this call: they belong to no stream -- the joined way)
+            deferred = false;
+    }
+    if (h->deferred_pending && !(deferred && sig == h->deferred_sig)) {
+        // a channel may be about to change streams: everything the side streams carry first
+        // (its own earlier calls on another stream: the range logic above has made this stream wait for them and their side streams)
+        PSK_HIP(deferred_join(h, stream));
+    }
     {
         uint32_t *hdr = psk::plan_header(h->h_plans[slot]);
         hdr[0] = 0u;                       // channels handed over: counted by the kernels
@@ -987,16 +1058,9 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_tiles,
                                           h->d_ts, h->d_test, stream));
         }
-        struct Cls {
-            int S, H;
-        };
-        Cls cls[33 * 8];
-        int n_cls = 0;
-        for (int k = 7; k >= 0; k--)
-            for (int S : kFastS)
-                if (need_SH[S][kClassH[k]])
-                    cls[n_cls++] = Cls{S, kClassH[k]};
-        const bool fork = n_cls > 1 && h->opt_fork;
+        if (any_quiet && deferred)  // (every launch set ends its own calls: the quiet channels' on the caller's stream)
+            PSK_HIP(psk::launch_seq(h->d_plans[slot], d_list + off_quiet, ch0, res.cnt_quiet, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+                                    h->lim.fit_cap, stream));
         if (fork) {
             if (!h->aux_fork) {
                 PSK_HIP(hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming));
@@ -1052,14 +1116,29 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             for (int exact = tiled_SH[S][H] ? 1 : 0; exact <= 1; exact++)
                 PSK_HIP(psk::launch_fast(S, class_H(H), exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
+            if (deferred)  // (the class's hand-overs are redone on its own stream, in front of its next call)
+                PSK_HIP(psk::launch_seq(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring, h->lim.ring_cap,
+                                        h->d_yv, h->lim.fit_cap, st));
         }
-        for (int a = 0; a < used_aux && a < kAuxStreams; a++) {
-            PSK_HIP(hipEventRecord(h->aux_join[a], h->aux[a]));
-            PSK_HIP(hipStreamWaitEvent(stream, h->aux_join[a], 0));
+        if (deferred) {
+            for (int a = 0; a < used_aux && a < kAuxStreams; a++) {
+                if (!h->slot_aux_ev[slot][a])
+                    PSK_HIP(hipEventCreateWithFlags(&h->slot_aux_ev[slot][a], hipEventDisableTiming));
+                PSK_HIP(hipEventRecord(h->slot_aux_ev[slot][a], h->aux[a]));
+                h->slot_aux_used[slot][a] = true;
+            }
+            h->deferred_pending = true;
+            h->deferred_sig = sig;
+            h->deferred_stream = stream;
+        } else {
+            for (int a = 0; a < used_aux && a < kAuxStreams; a++) {
+                PSK_HIP(hipEventRecord(h->aux_join[a], h->aux[a]));
+                PSK_HIP(hipStreamWaitEvent(stream, h->aux_join[a], 0));
+            }
+            if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
+                PSK_HIP(psk::launch_seq(h->d_plans[slot], nullptr, ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+                                        h->lim.fit_cap, stream));
         }
-        if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
-            PSK_HIP(psk::launch_seq(h->d_plans[slot], ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
-                                    h->lim.fit_cap, stream));
         if (tile_syms)
             PSK_HIP(hipEventRecord(h->tile_ev, stream));
         PSK_HIP(hipEventRecord(h->ev[slot], stream));
@@ -1424,9 +1503,37 @@ psk_soft_status psk_soft_synchronize(psk_soft_handle_t *h)
         if (h->ev_used[s])
             PSK_HIP(hipEventSynchronize(h->ev[s]));
     PSK_HIP(hipStreamSynchronize(h->stream));
+    for (int a = 0; a < kAuxStreams; a++)
+        if (h->aux[a])
+            PSK_HIP(hipStreamSynchronize(h->aux[a]));
+    if (h->deferred_pending && h->deferred_stream)
+        PSK_HIP(hipStreamSynchronize(h->deferred_stream));
+    h->deferred_pending = false;
+    for (auto &row : h->slot_aux_used)
+        for (bool &u : row) u = false;
     for (auto &sl : h->stage)
         if (sl.stream)
             PSK_HIP(hipStreamSynchronize(sl.stream));
+    return PSK_SOFT_OK;
+}
+
+psk_soft_status psk_soft_join(psk_soft_handle_t *h, void *stream_v)
+{
+    if (!h)
+        return fail(PSK_SOFT_ERR_INVALID_ARG, "null handle");
+    if (h->dry || !h->deferred_pending)
+        return PSK_SOFT_OK;
+    PSK_HIP(hipSetDevice(h->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : h->stream;
+    // (the caller's stream of the deferred calls carries one class itself: a third stream waits for it too)
+    if (h->deferred_stream && h->deferred_stream != stream) {
+        if (!h->aux_fork)
+            return PSK_SOFT_OK;
+        PSK_HIP(hipEventRecord(h->aux_fork, h->deferred_stream));
+        PSK_HIP(hipStreamWaitEvent(stream, h->aux_fork, 0));
+    }
+    h->deferred_pending = true;  // (deferred_join() clears it)
+    PSK_HIP(deferred_join(h, stream));
     return PSK_SOFT_OK;
 }
 
@@ -1503,6 +1610,14 @@ psk_soft_status psk_soft_set_option(psk_soft_handle_t *h, int option, int value)
     switch (option) {
     case PSK_SOFT_OPT_QPSK_SIGN_BITMAP: h->opt_qpsk_sign_map = value != 0; return PSK_SOFT_OK;
     case PSK_SOFT_OPT_CONCURRENT_CLASSES: h->opt_fork = value != 0; return PSK_SOFT_OK;
+    case PSK_SOFT_OPT_DEFERRED_JOIN:
+        if (!value && h->deferred_pending && !h->dry) {
+            const psk_soft_status st = psk_soft_synchronize(h);
+            if (st != PSK_SOFT_OK)
+                return st;
+        }
+        h->opt_deferred = value != 0;
+        return PSK_SOFT_OK;
     case PSK_SOFT_OPT_TIME_TILED:
         if (value < 0 || value > 2)
             return fail(PSK_SOFT_ERR_INVALID_ARG, "psk_soft_set_option: PSK_SOFT_OPT_TIME_TILED takes 0, 1 or 2");

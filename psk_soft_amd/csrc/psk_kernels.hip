@@ -156,7 +156,7 @@ __device__ void seq_emit_symbol(SeqEmit &E, cf32 sample, int sampleIndex, bool h
     }
 }
 
-__global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict__ plans, uint32_t ch0,
+__global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                      ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                      uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap)
 {
@@ -169,8 +169,11 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         if (hdr[0] == 0u && hdr[1] == 0u)
             return;  // no channel planned for this kernel, none handed over (psk_plan.h)
     }
-    const ChanPlan &p = plans[blockIdx.x];
-    const uint32_t ch = ch0 + blockIdx.x;
+    // (list: the channels of one launch set, where the window classes of a batch end their calls on streams of their own --
+    // psk_capi.cpp, deferred join --; null: every channel of the batch)
+    const uint32_t bi = list ? list[blockIdx.x] : blockIdx.x;
+    const ChanPlan &p = plans[bi];
+    const uint32_t ch = ch0 + bi;
     ChanState *st = &states[ch];
     const bool redo = (p.mode == PLAN_FAST) && (st->guard == 1u);  // both wave-scan kernels refused
     if (!(p.mode == PLAN_SEQ || p.mode == PLAN_SEQ_S1 || redo))
@@ -444,12 +447,12 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_seq(const ChanPlan *plans, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+hipError_t launch_seq(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
                       uint32_t ring_cap, float *yvs, uint32_t fit_cap, hipStream_t stream)
 {
     if (!nch)
         return hipSuccess;
-    hipLaunchKernelGGL(psk_seq_kernel, dim3(nch), dim3(kWave), 0, stream, plans, ch0, states, rings, ring_cap, yvs,
+    hipLaunchKernelGGL(psk_seq_kernel, dim3(nch), dim3(kWave), 0, stream, plans, list, ch0, states, rings, ring_cap, yvs,
                        fit_cap);
     return hipGetLastError();
 }

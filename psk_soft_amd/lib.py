@@ -118,6 +118,7 @@ EXPORTS = (
     "psk_soft_process_device",
     "psk_soft_process_host",
     "psk_soft_synchronize",
+    "psk_soft_join",
     "psk_soft_get_stats",
     "psk_soft_set_force_sequential",
     "psk_soft_state_bytes",
@@ -160,6 +161,7 @@ def load():
     L.psk_soft_process_device.argtypes = [vp, u32, u32, ctypes.POINTER(Packet), ctypes.POINTER(Output), vp]
     L.psk_soft_process_host.argtypes = [vp, u32, u32, ctypes.POINTER(Packet), ctypes.POINTER(Output)]
     L.psk_soft_synchronize.argtypes = [vp]
+    L.psk_soft_join.argtypes = [vp, vp]
     L.psk_soft_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.psk_soft_get_channel_stats.argtypes = [vp, u32, u32, ctypes.POINTER(Stats)]
     L.psk_soft_set_force_sequential.argtypes = [vp, i32]
@@ -261,6 +263,7 @@ class Handle:
     OPT_QPSK_SIGN_BITMAP = 1
     OPT_CONCURRENT_CLASSES = 2
     OPT_TIME_TILED = 3  # 0 never, 1 where it pays (default), 2 wherever the kernels exist
+    OPT_DEFERRED_JOIN = 5  # mixed window classes: the side streams are joined by join() / synchronize(), not by every call
     OPT_PARALLEL_FIT = 4  # tiled calls: 0 fit block by block, 1 parallel fit with the second round on demand (default), 2 always
 
     def set_option(self, option, value):
@@ -377,6 +380,10 @@ class Handle:
 
     def synchronize(self):
         _check(self._L.psk_soft_synchronize(self._h))
+
+    def join(self, stream=None):
+        """OPT_DEFERRED_JOIN: `stream` (a raw hipStream_t; None = the handle's own) waits for the handle's side streams."""
+        _check(self._L.psk_soft_join(self._h, ctypes.c_void_p(stream) if stream else None))
 
     def probe_read_ms(self, dev_ptr, nbytes, reps=5):
         """Mean duration (ms) of one pure 16-byte-load pass over a device buffer (empirical read ceiling)."""

@@ -1206,3 +1206,84 @@ def test_round1_one_ulp_case_is_bit_identical_now(oracle_mod):
     assert st["channels_fast"] == 1 and st["channels_sequential"] == 0, st
     assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "seed 702 / round 0 / channel 69")
     assert g["phase"].view(np.uint32)[10452] == r.phase.view(np.uint32)[10452]
+
+
+def test_deferred_join_of_mixed_window_classes(oracle_mod):
+    """PSK_SOFT_OPT_DEFERRED_JOIN: a batch that mixes window classes ends every class's calls on a stream of its own and joins
+    them only when asked to (psk_soft_join / psk_soft_synchronize).  Eight calls issued back to back without a host wait in
+    between, each into buffers of its own (an input or output touched out of order would show); in the middle a few channels
+    change their window class (the library has to join before their next call: they move to another stream) and one call
+    lacks a channel's packet (it runs the joined way).  Every channel of every call against the oracle, bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    S, C, calls, n = 8, 384, 8, 6000
+    Ms = [(2, 4, 8)[c % 3] for c in range(C)]
+    props = [dict(samplesPerBaud=S, constelationSize=Ms[c], numAvg=(25, 100, 200, 400)[(c // 3) % 4], phaseAvg=(10, 50, 200)[(c // 12) % 3])
+             for c in range(C)]
+    with ThreadPoolExecutor(8) as ex:
+        host = np.stack(list(ex.map(lambda c: synth_channel(9100 + c, Ms[c], S, calls * n), range(C))))
+    cap = (n // S + 2 + 63) // 64 * 64
+    h = pl.Handle(C, device=0)
+    h.configure(0, props)
+    h.set_option(pl.Handle.OPT_DEFERRED_JOIN, 1)
+    row_in = 2 * n * 4
+    d_in = h.device_alloc(calls * C * row_in)
+    d_soft, d_phase = h.device_alloc(calls * C * cap * 8), h.device_alloc(calls * C * cap * 4)
+    d_sidx, d_bits = h.device_alloc(calls * C * cap * 2), h.device_alloc(calls * C * cap * 6)
+    moved = {7: 400, 100: 25, 205: 100}  # channel -> new numAvg, from call 4 on
+    absent = (5, 33)                     # (call, channel) without a packet
+    outs = []
+    try:
+        stage = np.ascontiguousarray(host.reshape(C, calls, 2 * n).transpose(1, 0, 2))
+        h.upload(d_in, stage)
+        h.synchronize()
+        for k in range(calls):
+            if k == 4:
+                for c, A in moved.items():
+                    props[c] = dict(props[c], numAvg=A)
+                    h.configure(c, [props[c]])
+            pk, out = (pl.Packet * C)(), (pl.Output * C)()
+            for c in range(C):
+                base = k * C + c
+                pk[c].data, pk[c].n_floats, pk[c].sri_xdelta, pk[c].sri_mode = d_in + base * row_in, 2 * n, 0.01, 1
+                pk[c].sriChanged, pk[c].present = int(k == 0), int((k, c) != absent)
+                out[c].soft, out[c].bits = d_soft + base * cap * 8, d_bits + base * cap * 6
+                out[c].phase, out[c].sampleIndex, out[c].cap_symbols = d_phase + base * cap * 4, d_sidx + base * cap * 2, cap
+            h.process_device(0, pk, out)  # (no wait: the next call is issued while this one's classes are running)
+            outs.append(out)
+        h.join()
+        h.synchronize()
+        st = h.stats()
+        assert st["channels_sequential"] == 0, st
+        soft = h.download(d_soft, (calls, C, 2 * cap), np.float32)
+        phase = h.download(d_phase, (calls, C, cap), np.float32)
+        sidx = h.download(d_sidx, (calls, C, cap), np.int16)
+        bits = h.download(d_bits, (calls, C, 3 * cap), np.int16)
+    finally:
+        for p in (d_in, d_soft, d_phase, d_sidx, d_bits):
+            h.device_free(p)
+        h.close()
+
+    def check(c):
+        o = oracle_mod.OracleComponent()
+        first = dict(props[c], numAvg=(25, 100, 200, 400)[(c // 3) % 4])
+        for kk, v in first.items():
+            setattr(o, kk, v)
+        b = {2: 1, 4: 2, 8: 3}[Ms[c]]
+        for k in range(calls):
+            if k == 4 and c in moved:
+                o.numAvg = moved[c]
+            if (k, c) == absent:
+                assert int(outs[k][c].n_symbols) == 0
+                continue
+            r = o.service(host[c, 2 * n * k : 2 * n * (k + 1)], 0.01, sriChanged=(k == 0))
+            ns = int(outs[k][c].n_symbols)
+            assert ns == r.soft.size // 2, (c, k)
+            assert_parity(dict(soft=soft[k, c, : 2 * ns], phase=phase[k, c, :ns], index=sidx[k, c, :ns], bits=bits[k, c, : b * ns]),
+                          dict(soft=r.soft, phase=r.phase, index=r.index, bits=r.bits), "deferred join, channel %d call %d" % (c, k))
+
+    for c in range(C):
+        check(c)
