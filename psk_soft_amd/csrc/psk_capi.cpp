@@ -409,6 +409,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_DEFERRED_JOIN"))  // (as psk_soft_set_option(PSK_SOFT_OPT_DEFERRED_JOIN))
+        h->opt_deferred = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_STAMP"))
         h->opt_stamp = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_PARALLEL_FIT"))
@@ -1461,6 +1463,8 @@ psk_soft_status psk_soft_process_host(psk_soft_handle_t *h, uint32_t ch0, uint32
         if (oi)
             PSK_HIP(hipMemcpyAsync(d_in, h_in, oi, hipMemcpyHostToDevice, sl.stream));
         status = psk_soft_process_device(h, ch0 + first, n, dp.data(), dout.data(), sl.stream);
+        if (status == PSK_SOFT_OK)  // (deferred join: the downloads below read what the side streams write)
+            PSK_HIP(deferred_join(h, sl.stream));
         if (status != PSK_SOFT_OK)
             break;
         for (uint32_t i = 0; i < n; i++) {
