@@ -35,7 +35,7 @@ hipError_t launch_read_probe(const void *src, uint64_t bytes, float *sink, hipSt
 bool tile_front_has(int S, int H);
 hipError_t launch_tile_front(int S, int H, const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
                              const ChanState *states, const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw,
-                             float2 *t_s, PfChan *pf_chan, hipStream_t stream);
+                             float2 *t_s, PfChan *pf_chan, uint32_t tile0, hipStream_t stream);
 hipError_t launch_tile_front_any(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, uint32_t max_S,
                                  const ChanState *states, const float2 *rings, uint32_t ring_cap, TileInfo *tiles, float *t_raw, float2 *t_s,
                                  PfChan *pf_chan, hipStream_t stream);
@@ -45,8 +45,14 @@ hipError_t launch_tile_fit(const ChanPlan *plans, const uint32_t *list, uint32_t
 hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, ChanState *states,
                        float2 *rings, uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
                        const float2 *t_s, float *t_est, const PfScratch &sc, bool second_round, hipStream_t stream);
+hipError_t launch_tile_fit_range(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+                                 uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
+                                 const float2 *t_s, float *t_est, void *carry, float *carry_y, uint32_t tile0, uint32_t ntiles,
+                                 hipStream_t stream);
+size_t pipe_carry_bytes();
 hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
-                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream);
+                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, uint32_t tile0,
+                            uint32_t early, hipStream_t stream);
 }  // namespace psk
 
 namespace {
@@ -211,6 +217,11 @@ inline int class_H(int Hi) { return Hi > 8 ? Hi - 8 : Hi; }
 // tiles of 2 .. 16 blocks, as many as make kTiledTargetTiles tiles
 constexpr uint32_t kTiledFewChannels = 64, kTiledMinBlocksFew = 16, kTiledMaxChannels = 512, kTiledMinBlocks = 192;
 constexpr uint64_t kTiledTargetTiles = 4096;
+// the pipelined mode of the time-tiled path (front / fit / back of consecutive ranges of tiles on three streams, psk_tile.hip:
+// psk_tile_fit_range_kernel): window classes of a few hundred to a few thousand channels with long calls
+constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 3072, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
+constexpr size_t kPipeMaxSymbols = (size_t)1 << 27;  // (52 bytes of scratch a symbol)
+constexpr int kPipeEvents = 2 * (int)kPipeMaxRanges + 2;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                       18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
@@ -290,6 +301,12 @@ struct psk_soft_handle {
                            // 2 = the second round of the parallel fit is always enqueued (tests), 1 = for a while after
                            // a call reported a first guess that failed (pf.hint, a word the kernels write into page-locked memory)
     int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
+    int opt_pipe = 1;                       // PSK_SOFT_PIPELINED=0 (environment): never the pipelined mode (A/B runs)
+    hipStream_t pipe_st[2] = {};            // its fit and back streams (the front stage stays on the class's stream)
+    hipEvent_t pipe_ev[kPipeEvents] = {};
+    void *d_pipe_carry = nullptr;           // per channel of a pipelined launch: the fit state between two ranges (PipeCarry)
+    float *d_pipe_y = nullptr;              // ... and its ring of unwrapped phases
+    size_t pipe_cap = 0;
     hipEvent_t tile_ev = nullptr;
     hipStream_t tile_stream = nullptr;  // stream of the last call that used the scratch
     bool tile_ev_used = false;
@@ -409,6 +426,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_PIPELINED"))
+        h->opt_pipe = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_DEFERRED_JOIN"))  // (as psk_soft_set_option(PSK_SOFT_OPT_DEFERRED_JOIN))
         h->opt_deferred = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_STAMP"))
@@ -521,6 +540,15 @@ psk_soft_status psk_soft_destroy(psk_soft_handle_t *h)
             if (h->aux_join[k]) (void)hipEventDestroy(h->aux_join[k]);
             if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
         }
+        for (hipStream_t &q : h->pipe_st)
+            if (q) {
+                (void)hipStreamSynchronize(q);
+                (void)hipStreamDestroy(q);
+            }
+        for (hipEvent_t &e : h->pipe_ev)
+            if (e) (void)hipEventDestroy(e);
+        if (h->d_pipe_carry) (void)hipFree(h->d_pipe_carry);
+        if (h->d_pipe_y) (void)hipFree(h->d_pipe_y);
         if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
         for (auto &row : h->slot_aux_ev)
             for (hipEvent_t &e : row)
@@ -893,23 +921,48 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             tile_syms += (size_t)nb * 128u;
         }
     }
+    bool piped_SH[33][17] = {};
+    uint32_t pipe_tiles_SH[33][17] = {};  // tiles of a range
+    size_t pipe_need = 0;
     if (h->opt_tiled) {
         for (int S : kFastS)
             for (int H : kClassH) {
                 if (!res.need_SH[S][H] || !psk::tile_front_has(S, class_H(H)))
                     continue;
-                if (h->opt_tiled == 1 && !((res.cnt_SH[S][H] <= kTiledFewChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocksFew) ||
-                                           (res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks)))
+                // pipelined: the serial fit of a range under the front stage of the next (see kPipeMinChannels)
+                // (PSK_SOFT_PIPELINED=2, tests: wherever the kernels allow it, a few blocks to a range)
+                const bool pipe = (h->opt_pipe == 2 ? res.max_blocks_SH[S][H] >= 4u
+                                                    : h->opt_pipe && h->opt_tiled == 1 && res.cnt_SH[S][H] >= kPipeMinChannels &&
+                                                          res.cnt_SH[S][H] <= kPipeMaxChannels && res.max_blocks_SH[S][H] >= kPipeMinBlocks) &&
+                                  !cont && res.max_n[S][H] + 128u <= kPipeMaxYLen && (size_t)res.blocks_SH[S][H] * 128u <= kPipeMaxSymbols;
+                if (!pipe && h->opt_tiled == 1 &&
+                    !((res.cnt_SH[S][H] <= kTiledFewChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocksFew) ||
+                      (res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks)))
                     continue;
                 uint64_t K = res.blocks_SH[S][H] / kTiledTargetTiles;
                 K = K < 2 ? 2 : K > 16 ? 16 : K;
                 tiled_SH[S][H] = true;
+                if (pipe) {
+                    piped_SH[S][H] = true;
+                    const uint32_t T = (uint32_t)((res.max_blocks_SH[S][H] + K - 1) / K);
+                    uint32_t tr = (uint32_t)(kTiledTargetTiles / res.cnt_SH[S][H]);  // (a range = about one machine-load of tiles)
+                    tr = tr < 1u ? 1u : tr;
+                    if (h->opt_pipe == 2 && tr > 3u)
+                        tr = 3u;
+                    if (const char *e = std::getenv("PSK_SOFT_PIPE_RANGE_TILES"))  // (A/B runs)
+                        tr = std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : tr;
+                    if ((T + tr - 1) / tr > kPipeMaxRanges)
+                        tr = (T + kPipeMaxRanges - 1) / kPipeMaxRanges;
+                    pipe_tiles_SH[S][H] = tr;
+                    if (off_SH[S][H] + res.cnt_SH[S][H] > pipe_need)
+                        pipe_need = off_SH[S][H] + res.cnt_SH[S][H];
+                }
                 tiles_max_SH[S][H] = (uint32_t)((res.max_blocks_SH[S][H] + K - 1) / K);
                 for (uint32_t i = 0; i < res.cnt_SH[S][H]; i++) {
                     psk::ChanPlan &p = plans[h_list[off_SH[S][H] + i]];
                     const uint64_t nb = (p.n_out + 127u) / 128u;
                     p.lf_flags |= psk::PLAN_TILED;
-                    if (h->opt_pfit && p.lf_len0 == p.lf_n && p.lf_n >= 2)
+                    if (!pipe && h->opt_pfit && p.lf_len0 == p.lf_n && p.lf_n >= 2)
                         p.lf_flags |= psk::PLAN_PFIT;
                     p.tile_blocks = (uint32_t)K;
                     p.tile_base = (uint32_t)tile_count;
@@ -961,6 +1014,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 res.cnt_any = 0;
                 for (auto &row : tiled_SH)
                     for (bool &t : row) t = false;
+                for (auto &row : piped_SH)
+                    for (bool &t : row) t = false;
                 tile_syms = 0;
             } else {
                 h->tile_cap = cnt;
@@ -982,6 +1037,35 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         pf_second = h->opt_pfit == 2 || h->pf_second_ttl > 0;
         if (h->tile_ev_used && h->tile_stream != stream)  // the scratch is one per handle
             PSK_HIP(hipStreamWaitEvent(stream, h->tile_ev, 0));
+        if (pipe_need) {
+            // the pipelined mode's own scratch (one PipeCarry and one ring of kPipeMaxYLen floats per channel of a launch) and its
+            // two streams -- of another priority than the caller's, so that they get hardware queues of their own
+            if (pipe_need > h->pipe_cap) {
+                PSK_HIP(hipDeviceSynchronize());
+                if (h->d_pipe_carry) (void)hipFree(h->d_pipe_carry);
+                if (h->d_pipe_y) (void)hipFree(h->d_pipe_y);
+                h->d_pipe_carry = nullptr, h->d_pipe_y = nullptr, h->pipe_cap = 0;
+                const size_t cap = pipe_need + pipe_need / 4;
+                if (hipMalloc(&h->d_pipe_carry, psk::pipe_carry_bytes() * cap) == hipSuccess &&
+                    hipMalloc((void **)&h->d_pipe_y, sizeof(float) * kPipeMaxYLen * cap) == hipSuccess) {
+                    h->pipe_cap = cap;
+                } else {  // (out of device memory: the one-launch kernels do without)
+                    (void)hipGetLastError();
+                    if (h->d_pipe_carry) (void)hipFree(h->d_pipe_carry);
+                    h->d_pipe_carry = nullptr;
+                    for (auto &row : piped_SH)
+                        for (bool &t : row) t = false;
+                }
+            }
+            if (!h->pipe_st[0]) {
+                int prio_lo = 0, prio_hi = 0;
+                PSK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                // (CU-masked streams for the stages -- the serial ones on every n-th CU, the front stage on the others -- were measured:
+                // no gain, 2.77 ... 2.84 against 2.75 ms at 512 channels)
+                for (hipStream_t &q : h->pipe_st) PSK_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio_hi));
+                for (hipEvent_t &e : h->pipe_ev) PSK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+        }
     }
     // window classes of the call in launch order (deepest history first); class 0 stays on the caller's stream, the others take
     // the side streams in turn
@@ -1058,7 +1142,7 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, h->d_state, h->d_ring, h->lim.ring_cap,
                                          h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, h->pf, stream));
             PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_tiles,
-                                          h->d_ts, h->d_test, stream));
+                                          h->d_ts, h->d_test, 0u, 0u, stream));
         }
         if (any_quiet && deferred)  // (every launch set ends its own calls: the quiet channels' on the caller's stream)
             PSK_HIP(psk::launch_seq(h->d_plans[slot], d_list + off_quiet, ch0, res.cnt_quiet, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
@@ -1098,11 +1182,42 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             }
             const uint32_t y_len = ring_floats(max_n[S][H], psk::ering_dynamic(S) ? 256u : 512u);
             const uint32_t r_len = class_H(H) == 1 ? ((max_A[S][H] + 128u + 1u) & ~1u) : 0u;
-            if (tiled_SH[S][H]) {
+            if (tiled_SH[S][H] && piped_SH[S][H]) {
+                // pipelined: front(range j) here, fit(range j) on a second stream behind it -- under front(range j + 1) --,
+                // back(range j) on a third behind that (psk_tile.hip: psk_tile_fit_range_kernel)
+                const uint32_t cnt = res.cnt_SH[S][H], T = tiles_max_SH[S][H], tr = pipe_tiles_SH[S][H];
+                const uint32_t *const l = d_list + off_SH[S][H];
+                char *const carry = static_cast<char *>(h->d_pipe_carry) + psk::pipe_carry_bytes() * off_SH[S][H];
+                float *const carry_y = h->d_pipe_y + (size_t)kPipeMaxYLen * off_SH[S][H];
+                const uint32_t y_pipe = ring_floats(max_n[S][H], 512u);
+                int e = 0;
+                PSK_HIP(hipEventRecord(h->pipe_ev[e], st));  // (the side streams start behind everything this one carries)
+                PSK_HIP(hipStreamWaitEvent(h->pipe_st[0], h->pipe_ev[e], 0));
+                PSK_HIP(hipStreamWaitEvent(h->pipe_st[1], h->pipe_ev[e], 0));
+                e++;
+                for (uint32_t t0 = 0; t0 < T; t0 += tr) {
+                    const uint32_t nt = T - t0 < tr ? T - t0 : tr;
+                    PSK_HIP(psk::launch_tile_front(S, class_H(H), h->d_plans[slot], l, ch0, cnt, nt, h->d_state, h->d_ring, h->lim.ring_cap, r_len,
+                                                   h->d_tiles, h->d_traw, h->d_ts, h->pf.chan, t0, st));
+                    PSK_HIP(hipEventRecord(h->pipe_ev[e], st));
+                    PSK_HIP(hipStreamWaitEvent(h->pipe_st[0], h->pipe_ev[e], 0));
+                    e++;
+                    PSK_HIP(psk::launch_tile_fit_range(h->d_plans[slot], l, ch0, cnt, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
+                                                       h->lim.fit_cap, y_pipe, h->d_tiles, h->d_traw, h->d_ts, h->d_test, carry, carry_y, t0, nt,
+                                                       h->pipe_st[0]));
+                    PSK_HIP(hipEventRecord(h->pipe_ev[e], h->pipe_st[0]));
+                    PSK_HIP(hipStreamWaitEvent(h->pipe_st[1], h->pipe_ev[e], 0));
+                    e++;
+                    PSK_HIP(psk::launch_tile_back(h->d_plans[slot], l, ch0, cnt, nt, h->d_state, h->d_tiles, h->d_ts, h->d_test, t0, 1u,
+                                                  h->pipe_st[1]));
+                }
+                PSK_HIP(hipEventRecord(h->pipe_ev[e], h->pipe_st[1]));  // (behind the last fit too: the last back waited for it)
+                PSK_HIP(hipStreamWaitEvent(st, h->pipe_ev[e], 0));
+            } else if (tiled_SH[S][H]) {
                 // (a call these cannot carry comes out with guard 1 and nothing committed: the launches below redo it)
                 PSK_HIP(psk::launch_tile_front(S, class_H(H), h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
                                                h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts,
-                                               h->pf.chan, st));
+                                               h->pf.chan, 0u, st));
                 if (h->opt_pfit)
                     PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                              h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts,
@@ -1111,7 +1226,7 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                                              h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test,
                                              h->pf, st));
                 PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
-                                              h->d_tiles, h->d_ts, h->d_test, st));
+                                              h->d_tiles, h->d_ts, h->d_test, 0u, 0u, st));
             }
             // (the exact tier only works on the calls the tier in front of it left; behind the time-tiled kernels, whose front
             // stage IS the screened timing, it is the exact tier that picks up what they hand over)

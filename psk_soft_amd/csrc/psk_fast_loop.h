@@ -1381,8 +1381,10 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         // priority, the arithmetic half (pow, atan2f, fit, sincosf) at normal: requests go out early
         // (measured -1 %; requesting the samples a whole block ahead measured +1.5 %, touching the next block's
         // lines with a one-dword load per lane half a block ahead +9 %: the loads in flight are not the limit)
+        // (the front stage of the time-tiled path stays below the serial fit stage, which in the pipelined mode runs beside it
+        // on the same SIMDs at priority 3: psk_tile.hip)
         if constexpr (!PSK_PACE_ON(FRONT, EXACT))
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(FRONT ? 1 : 3);
         uint32_t pace_row = 0u;
         // (wave-uniform; a call of a few blocks looks every block: it is over before the fourth)
 #if PSK_PACE_SHORT_MODE == 1

@@ -589,6 +589,199 @@ __global__ __launch_bounds__(64) void psk_tile_fit_kernel(const ChanPlan *__rest
     }
 }
 
+// ---- fit, a range of tiles at a time: the pipelined mode (psk_capi.cpp) ----
+// For a few hundred to a couple of thousand channels the serial fit (1.5 us a block and channel, whatever the company) and the
+// machine-filling front stage take about as long as each other; one after the other they add up.  The host therefore cuts the
+// call's tiles into ranges of about one machine-load and launches  front(range j)  on one stream,  fit(range j)  on a second
+// behind it,  back(range j)  on a third behind that: the fit of range j runs under the front stage of range j + 1.  Between
+// two launches a channel's fit state waits in scratch (PipeCarry: the FastCarry of every lane, what the fold over the tiles
+// has seen so far, and the LDS ring of unwrapped phases); the launch that reaches the channel's last tile ends the call exactly
+// as the one-launch fit kernel does.
+struct PipeCarry {
+    FastCarry cy[kWave];
+    unsigned umax, umin1, refuse, gap_b, cap_b, wmax_b;
+    int exact_blocks;
+    float emax;
+    float last0_re, last0_im;
+    uint32_t dead;  // a launch of this call has handed the channel over: the later ones leave it alone
+    uint32_t pad;
+};
+__global__ __launch_bounds__(64) void psk_tile_fit_range_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+                                                                ChanState *__restrict__ states, float2 *__restrict__ rings, uint32_t ring_cap,
+                                                                float *__restrict__ yvs, uint32_t fit_cap, uint32_t y_len,
+                                                                TileInfo *__restrict__ tiles, const float *__restrict__ t_raw,
+                                                                const float2 *__restrict__ t_s, float *__restrict__ t_est,
+                                                                PipeCarry *__restrict__ carry, float *__restrict__ carry_y, uint32_t tile0,
+                                                                uint32_t ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float *const yring = lds_dyn;
+    const uint32_t ymask = y_len - 1u;
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = list[blockIdx.x];
+    const ChanPlan &p = plans[bi];
+    if (!tile_plan_mine(p))
+        return;
+    const uint32_t ch = ch0 + bi;
+    ChanState *st = &states[ch];
+    const int n_out = (int)p.n_out;
+    const int n_blocks = (n_out + kB - 1) / kB;
+    const int n_tiles = (n_blocks + (int)p.tile_blocks - 1) / (int)p.tile_blocks;
+    if ((int)tile0 >= n_tiles)
+        return;  // (the channel's call ended in an earlier range)
+    const int t_end = (int)(tile0 + ntiles) < n_tiles ? (int)(tile0 + ntiles) : n_tiles;
+    const bool first = tile0 == 0u, last = t_end == n_tiles;
+    TileInfo *const ti = tiles + p.tile_base;
+    PipeCarry &pc = carry[blockIdx.x];
+    float *const ysave = carry_y + (size_t)blockIdx.x * y_len;
+    if (!first && pc.dead)
+        return;
+
+    // what the front stage reports about this range's tiles, folded into what the earlier ranges left (tile_fold, range by range)
+    float emax = first ? 0.0f : pc.emax;
+    unsigned umax = first ? 0u : pc.umax, umin1 = first ? 0xFFFFFFFFu : pc.umin1, refuse_b = first ? 0u : pc.refuse;
+    unsigned gap_b = first ? 0x7F800000u : pc.gap_b, cap_b = first ? 0x7F800000u : pc.cap_b, wmax_b = first ? 0u : pc.wmax_b;
+    int exact_blocks = 0;
+    for (int j = (int)tile0 + lane; j < t_end; j += kWave) {
+        const TileInfo t = ti[j];
+        umax = t.umax > umax ? t.umax : umax;
+        umin1 = t.umin1 < umin1 ? t.umin1 : umin1;
+        refuse_b |= t.refuse;
+        const unsigned g = __float_as_uint(t.gap_rel), cp = __float_as_uint(t.cap), w = __float_as_uint(t.wmax);
+        gap_b = g < gap_b ? g : gap_b;
+        cap_b = cp < cap_b ? cp : cap_b;
+        wmax_b = w > wmax_b ? w : wmax_b;
+        exact_blocks += (int)t.stat_exact;
+        emax = __builtin_fmaxf(emax, t.emax);
+    }
+    emax = wave_max_f32(__builtin_fmaxf(emax, 0.0f));
+    umax = wave_max_u32(umax);
+    umin1 = wave_min_u32(umin1);
+    gap_b = wave_min_u32(gap_b);
+    cap_b = wave_min_u32(cap_b);
+    wmax_b = wave_max_u32(wmax_b);
+    exact_blocks = __builtin_amdgcn_readlane(wave_scan_i32(exact_blocks), 63) + (first ? 0 : pc.exact_blocks);
+    bool refuse = __any(refuse_b != 0u);
+    {   // (the verdict of tile_fold on everything seen so far: a later range can only make it stricter)
+        const float wmax = __uint_as_float(wmax_b);
+        if (!(wmax <= __uint_as_float(cap_b)) && !(wmax < 1.0e-37f))
+            refuse = true;
+        const bool ambiguous = !(__uint_as_float(gap_b) > wmax);
+        if (umin1 != 0xFFFFFFFFu && ambiguous) {
+            int eh = (int)(umax >> 23), el = (int)((umin1 + 1u) >> 23);
+            eh = eh < 1 ? 1 : eh;
+            el = el < 1 ? 1 : el;
+            const int terms_log2 = 32 - __builtin_clz((unsigned)(p.A + 2u * kB));
+            if (24 + (eh - el) + terms_log2 > 52)
+                refuse = true;
+        }
+    }
+    auto hand_over = [&]() {
+        if (lane == 0) {
+            st->emax_hint = emax;
+            st->guard = 1u;
+            atomicAdd(p.handed_over, 1u);
+            pc.dead = 1u;
+        }
+    };
+    if (refuse) {
+        hand_over();
+        return;
+    }
+
+    float2 *ring_base = rings + (size_t)ch * 2u * ring_cap;
+    const float2 *ring_src = ring_base + (size_t)p.ring_src * ring_cap;
+    float2 *ring_dst = ring_base + (size_t)(p.ring_src ^ 1u) * ring_cap;
+    float *yv = yvs + (size_t)ch * fit_cap;
+    XView X;
+    X.ring = reinterpret_cast<const f2g *>(ring_src);
+    X.in = reinterpret_cast<const f2g *>(p.in);
+    X.L0 = p.ring_len0;
+
+    FastCarry cy;
+    float last0_re, last0_im;
+    if (first) {
+        call_prologue(p, st, yv, fit_cap, yring, ymask, lane, cy);
+        last0_re = cy.last_re, last0_im = cy.last_im;
+        if (lane == 0) {  // the back stage starts from the old `last`
+            ti[0].last0_re = last0_re;
+            ti[0].last0_im = last0_im;
+        }
+    } else {
+        cy = pc.cy[lane];
+        last0_re = pc.last0_re, last0_im = pc.last0_im;
+        for (uint32_t j = lane; j < y_len; j += kWave) yring[j] = ysave[j];
+        wave_lds_fence();
+    }
+
+    const uint32_t n = p.lf_n;
+    const float xd = p.lf_xdelta;
+    float den_s = cy.den, xavg_s = cy.xavg;
+    if (n > 1)
+        fit_denominator(xd, n, den_s, xavg_s);
+    const FitKnown fk = fit_known(xd, n, den_s, xavg_s);
+    const float *raw_row = t_raw + p.tile_off;
+    float *est_row = t_est + p.tile_off;
+    const int c0 = (int)tile0 * (int)p.tile_blocks;
+    const int c1 = last ? n_blocks : t_end * (int)p.tile_blocks;
+    __builtin_amdgcn_s_setprio(3);  // (the serial stage: the front stage's waves of the next range fill the gaps it leaves)
+    float2 nxt = *reinterpret_cast<const float2 *>(raw_row + c0 * kB + 2 * lane);
+    for (int c = c0; c < c1; c++) {
+        const int i0 = c * kB + 2 * lane;
+        const float raw[kR] = {nxt.x, nxt.y};
+        if (c + 1 < c1)
+            nxt = *reinterpret_cast<const float2 *>(raw_row + i0 + kB);
+        const bool valid[kR] = {i0 < n_out, i0 + 1 < n_out};
+        const int rem = n_out - c * kB;
+        const int nvalid = rem < kB ? rem : kB;
+        const int lane_last = (nvalid - 1) >> 1, r_last = (nvalid - 1) & 1;
+        float est[kR];
+        fit_stage<false>(c, lane, n, xd, den_s, xavg_s, fk, valid, raw, nvalid, lane_last, r_last, yring, ymask, cy, est);
+        if (__any(cy.refuse)) {
+            hand_over();
+            return;
+        }
+        *reinterpret_cast<float2 *>(est_row + i0) = make_float2(est[0], est[1]);  // (rows padded to whole blocks)
+    }
+
+    if (!last) {
+        pc.cy[lane] = cy;
+        wave_lds_fence();
+        for (uint32_t j = lane; j < y_len; j += kWave) ysave[j] = yring[j];
+        if (lane == 0) {
+            pc.umax = umax, pc.umin1 = umin1, pc.refuse = refuse_b ? 1u : 0u, pc.gap_b = gap_b, pc.cap_b = cap_b, pc.wmax_b = wmax_b;
+            pc.exact_blocks = exact_blocks;
+            pc.emax = emax;
+            pc.last0_re = last0_re, pc.last0_im = last0_im;
+            pc.dead = 0u;
+        }
+        return;
+    }
+    if (lane == 0)
+        st->emax_hint = emax;
+    cy.last_k = ti[n_tiles - 1].last_k;
+    cy.stat_exact_blocks = (uint32_t)exact_blocks;
+    if (p.diff) {  // psk_soft_i::last = the last sample output (cpp/psk_soft.cpp:486-491)
+        const float2 l = t_s[p.tile_off + (uint64_t)(n_out - 1)];
+        cy.last_re = l.x;
+        cy.last_im = l.y;
+    }
+    call_epilogue(p, st, yv, fit_cap, yring, ymask, X, ring_dst, lane, cy, kGuardTiled);
+}
+
+hipError_t launch_tile_fit_range(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, ChanState *states, float2 *rings,
+                                 uint32_t ring_cap, float *yvs, uint32_t fit_cap, uint32_t y_len, TileInfo *tiles, const float *t_raw,
+                                 const float2 *t_s, float *t_est, void *carry, float *carry_y, uint32_t tile0, uint32_t ntiles,
+                                 hipStream_t stream)
+{
+    if (!nch || !ntiles)
+        return hipSuccess;
+    hipLaunchKernelGGL(psk_tile_fit_range_kernel, dim3(nch), dim3(kWave), sizeof(float) * (size_t)y_len, stream, plans, list, ch0, states, rings,
+                       ring_cap, yvs, fit_cap, y_len, tiles, t_raw, t_s, t_est, static_cast<PipeCarry *>(carry), carry_y, tile0, ntiles);
+    return hipGetLastError();
+}
+size_t pipe_carry_bytes() { return sizeof(PipeCarry); }
+
 // ---- pf_begin: one wave per channel (psk_pfit.h) ----
 __global__ __launch_bounds__(64) void pf_begin_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       const ChanState *__restrict__ states, const float *__restrict__ yvs, uint32_t fit_cap,
@@ -611,16 +804,19 @@ __global__ __launch_bounds__(64) void pf_begin_kernel(const ChanPlan *__restrict
 // ---- back: grid (tiles, channels of the launch) ----
 __global__ __launch_bounds__(64) void psk_tile_back_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                            const ChanState *__restrict__ states, const TileInfo *__restrict__ tiles,
-                                                           const float2 *__restrict__ t_s, const float *__restrict__ t_est)
+                                                           const float2 *__restrict__ t_s, const float *__restrict__ t_est,
+                                                           uint32_t tile0, uint32_t early)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
-    if (!tile_plan_mine(p) || states[ch0 + bi].guard != kGuardTiled)
+    // (early: the pipelined mode writes a range's outputs as soon as its estimates are there, before the call is committed --
+    // a call that is handed over later on is redone from its first symbol, outputs included)
+    if (!tile_plan_mine(p) || (!early && states[ch0 + bi].guard != kGuardTiled))
         return;
     const int n_out = (int)p.n_out;
     const int n_blocks = (n_out + kB - 1) / kB;
-    const int c_begin = (int)(blockIdx.x * p.tile_blocks);
+    const int c_begin = (int)((blockIdx.x + tile0) * p.tile_blocks);
     if (c_begin >= n_blocks)
         return;
     const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
@@ -668,7 +864,7 @@ hipError_t launch_tile_front(int S, int H, PSK_TILE_FRONT_ARGS)
 {
 #define PSK_TCASE(Sv)       \
     if (S == Sv && H == 1) \
-        return launch_tile_front_S##Sv##_H1(plans, list, ch0, nch, max_tiles, states, rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan, stream);
+        return launch_tile_front_S##Sv##_H1(plans, list, ch0, nch, max_tiles, states, rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan, tile0, stream);
     PSK_TCASE(2) PSK_TCASE(3) PSK_TCASE(4) PSK_TCASE(5) PSK_TCASE(6) PSK_TCASE(7) PSK_TCASE(8) PSK_TCASE(9)
     PSK_TCASE(10) PSK_TCASE(11) PSK_TCASE(12) PSK_TCASE(13) PSK_TCASE(14) PSK_TCASE(15) PSK_TCASE(16)
     return hipErrorInvalidValue;
@@ -744,13 +940,14 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
 }
 
 hipError_t launch_tile_back(const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles,
-                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, hipStream_t stream)
+                            const ChanState *states, const TileInfo *tiles, const float2 *t_s, const float *t_est, uint32_t tile0,
+                            uint32_t early, hipStream_t stream)
 {
     if (!nch || !max_tiles)
         return hipSuccess;
     for (uint32_t off = 0; off < nch; off += kGridYMax) {
         const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
-        hipLaunchKernelGGL(psk_tile_back_kernel, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states, tiles, t_s, t_est);
+        hipLaunchKernelGGL(psk_tile_back_kernel, dim3(max_tiles, n), dim3(kWave), 0, stream, plans, list + off, ch0, states, tiles, t_s, t_est, tile0, early);
     }
     return hipGetLastError();
 }

@@ -9,6 +9,6 @@ namespace psk {
 hipError_t PSK_CAT(launch_tile_front_S, PSK_INST_S, _H, PSK_INST_H)(PSK_TILE_FRONT_ARGS)
 {
     return launch_tile_front_inst<PSK_INST_S, PSK_INST_H>(plans, list, ch0, nch, max_tiles, states, rings, ring_cap, r_len, tiles, t_raw,
-                                                          t_s, pf_chan, stream);
+                                                          t_s, pf_chan, tile0, stream);
 }
 }  // namespace psk

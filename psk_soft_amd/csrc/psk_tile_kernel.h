@@ -40,7 +40,8 @@ template <int SV, int HV>
 __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                             const ChanState *__restrict__ states, const float2 *__restrict__ rings,
                                                             uint32_t ring_cap, uint32_t r_len, TileInfo *__restrict__ tiles,
-                                                            float *__restrict__ t_raw, float2 *__restrict__ t_s, PfChan *__restrict__ pf_chan)
+                                                            float *__restrict__ t_raw, float2 *__restrict__ t_s, PfChan *__restrict__ pf_chan,
+                                                            uint32_t tile0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     constexpr bool kDyn = ering_dynamic(SV);
@@ -58,10 +59,11 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
     if (!tile_plan_mine(p) || p.S != (uint32_t)SV || hist_blocks_for(p.A) != HV)
         return;
     const int n_blocks = (int)((p.n_out + kB - 1) / kB);
-    const int c_begin = (int)(blockIdx.x * p.tile_blocks);
+    const uint32_t tile = blockIdx.x + tile0;  // (tile0: the launch covers a range of tiles -- the pipelined mode, psk_capi.cpp)
+    const int c_begin = (int)(tile * p.tile_blocks);
     if (c_begin >= n_blocks)
         return;
-    if (blockIdx.x == 0 && lane == 0)  // the call's entry in the parallel fit's bookkeeping (psk_pfit.h: PfChan) starts clean
+    if (tile == 0 && lane == 0)  // the call's entry in the parallel fit's bookkeeping (psk_pfit.h: PfChan) starts clean
         pf_chan[bi].fail = pf_chan[bi].done = pf_chan[bi].slow_blocks = pf_chan[bi].retry = 0u;
     const int c_end = c_begin + (int)p.tile_blocks < n_blocks ? c_begin + (int)p.tile_blocks : n_blocks;
     const uint32_t ch = ch0 + bi;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
     const bool refuse = __any(cy.refuse);
     const float emax = wave_max_f32(__builtin_fmaxf(cy.emax, 0.0f));
     if (lane == 0) {
-        TileInfo &t = tiles[p.tile_base + blockIdx.x];
+        TileInfo &t = tiles[p.tile_base + tile];
         t.umax = umax;
         t.umin1 = umin1;
         t.refuse = refuse ? 1u : 0u;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64) void psk_tile_front_kernel(const ChanPlan *__re
 #define PSK_TILE_FRONT_ARGS                                                                                                    \
     const ChanPlan *plans, const uint32_t *list, uint32_t ch0, uint32_t nch, uint32_t max_tiles, const ChanState *states,       \
         const float2 *rings, uint32_t ring_cap, uint32_t r_len, TileInfo *tiles, float *t_raw, float2 *t_s, PfChan *pf_chan,          \
-        hipStream_t stream
+        uint32_t tile0, hipStream_t stream
 
 template <int SV, int HV>
 hipError_t launch_tile_front_inst(PSK_TILE_FRONT_ARGS)
@@ -125,7 +127,7 @@ hipError_t launch_tile_front_inst(PSK_TILE_FRONT_ARGS)
     for (uint32_t off = 0; off < nch; off += kGridYMax) {  // (channels are the grid's y dimension: slices of 65535)
         const uint32_t n = nch - off < kGridYMax ? nch - off : kGridYMax;
         hipLaunchKernelGGL((psk_tile_front_kernel<SV, HV>), dim3(max_tiles, n), dim3(kWave), lds_bytes, stream, plans, list + off, ch0, states,
-                           rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan);
+                           rings, ring_cap, r_len, tiles, t_raw, t_s, pf_chan, tile0);
     }
     return hipGetLastError();
 }

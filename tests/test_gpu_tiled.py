@@ -2,6 +2,8 @@
 along time -- timing recovery and raw phase per tile, the feedback unwrap and fit one wave per channel, de-rotation
 and slicing per tile again.  Same bar as everywhere: all four streams carry the oracle's bits, whatever the
 packetisation; a call the tiles cannot vouch for is redone by the wave-scan kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -37,6 +39,11 @@ CASES = [
 ]
 
 
+# PSK_SOFT_PIPELINED=2 (environment) forces the pipelined mode of the time-tiled path on every call that can take it: the parity
+# assertions below then test THAT mode; the statistics that count the parallel fit do not apply
+PIPED = os.environ.get("PSK_SOFT_PIPELINED") == "2"
+
+
 @pytest.mark.parametrize("M,S,diff,A,n,N,packet", CASES)
 def test_tiled_single_channel(oracle_mod, M, S, diff, A, n, N, packet):
     from psk_soft_amd.stimulus import synth_channel
@@ -52,7 +59,7 @@ def test_tiled_single_channel(oracle_mod, M, S, diff, A, n, N, packet):
     if got["index"].size and (packet is None or packet > 8 * S):
         assert st["channels_tiled"] == 1, st
         # from the second call on the fit window is full: unwrap and fit go through the parallel path (psk_pfit.h)
-        if packet is not None and n >= 2:
+        if packet is not None and n >= 2 and not PIPED:
             assert st["channels_parallel_fit"] == 1 and st["parallel_fit_refusals"] == 0, st
     assert_parity(got, ref, "tiled M%d S%d diff%d A%d n%d N%d pkt%s" % (M, S, diff, A, n, N, packet))
     h.close()
@@ -396,4 +403,45 @@ def test_more_channels_than_a_grid_dimension(oracle_mod):
     for c in (0, 1, 7, 65534, 65535, 65536, C - 1):
         ref = oracle_run(oracle_mod, base[c % 8], dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=20))
         assert_parity(res[c], ref, "channel %d of %d" % (c, C))
+    h.close()
+
+
+@pytest.mark.parametrize("S,M,diff,n_ph", [(8, 4, 0, 50), (10, 8, 1, 200), (4, 2, 0, 10), (16, 4, 1, 300)])
+def test_pipelined_ranges(oracle_mod, monkeypatch, S, M, diff, n_ph):
+    """The pipelined mode of the time-tiled path (psk_tile.hip: psk_tile_fit_range_kernel): the call's tiles go out in ranges,
+    front / fit / back of consecutive ranges on three streams, the fit state of a channel waiting in scratch between two
+    launches.  Forced here on a small batch (PSK_SOFT_PIPELINED=2: ranges of three tiles): channels of ragged lengths (their
+    calls end in different ranges, some in the first), partial last blocks, differential decoding (the back stage's `last`),
+    several calls in a row (carried state), and one channel noisy enough to be handed over in the middle of a call (the later
+    ranges must leave it alone and the wave-scan kernels redo it).  All four streams against the oracle, bit for bit."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    monkeypatch.setenv("PSK_SOFT_PIPELINED", "2")
+    C, calls = 7, 3
+    lens = [40000, 40000, 1000 * S, 23456, 40000, 17 * 128 * S + 5 * S, 40000]
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n_ph, differentialDecoding=diff)
+    iqs = [synth_channel(500 + 7 * S + c, M, S, calls * lens[c], sigma=(0.35 if c == 4 else 0.01)) for c in range(C)]
+    h = _tiled_handle(C)
+    h.configure(0, [props] * C)
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
+    tiled = 0
+    for k in range(calls):
+        res = h.process_host(0, [dict(data=iqs[c][2 * k * lens[c] : 2 * (k + 1) * lens[c]], xdelta=0.01, sriChanged=(k == 0)) for c in range(C)])
+        st = h.stats()
+        assert st["channels_fast"] == C and st["channels_sequential"] == 0 and st["channels_parallel_fit"] == 0, st
+        tiled += st["channels_tiled"]
+        for c in range(C):
+            for key in got[c]:
+                got[c][key].append(res[c][key])
+    assert tiled >= calls * (C - 2), tiled  # (the noisy channel may be handed over; everything else stays on the tiled kernels)
+    for c in range(C):
+        o = oracle_mod.OracleComponent()
+        for kk, v in props.items():
+            setattr(o, kk, v)
+        ref = dict(soft=[], bits=[], phase=[], index=[])
+        for k in range(calls):
+            r = o.service(iqs[c][2 * k * lens[c] : 2 * (k + 1) * lens[c]], 0.01, sriChanged=(k == 0))
+            ref["soft"].append(r.soft); ref["bits"].append(r.bits); ref["phase"].append(r.phase); ref["index"].append(r.index)
+        assert_parity({key: np.concatenate(v) for key, v in got[c].items()}, {key: np.concatenate(v) for key, v in ref.items()},
+                      "pipelined S%d M%d ch%d" % (S, M, c))
     h.close()
