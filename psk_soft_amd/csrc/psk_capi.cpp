@@ -219,7 +219,7 @@ constexpr uint32_t kTiledFewChannels = 64, kTiledMinBlocksFew = 16, kTiledMaxCha
 constexpr uint64_t kTiledTargetTiles = 4096;
 // the pipelined mode of the time-tiled path (front / fit / back of consecutive ranges of tiles on three streams, psk_tile.hip:
 // psk_tile_fit_range_kernel): window classes of a few hundred to a few thousand channels with long calls
-constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 3072, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
+constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 1280, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
 constexpr size_t kPipeMaxSymbols = (size_t)1 << 27;  // (52 bytes of scratch a symbol)
 constexpr int kPipeEvents = 2 * (int)kPipeMaxRanges + 2;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS

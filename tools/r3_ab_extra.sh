@@ -6,7 +6,7 @@ cp $R/psk_soft_amd/libpsk_soft_hip.so /tmp/lib_orig.so
 cd $R/psk_soft_amd/csrc
 i=0
 for v in "$@"; do
-  rm -f obj/psk_fast_S8_H1_E0.o
+  rm -f obj/${OBJ:-psk_fast_S8_H1_E0}.o
   make -j16 EXTRA="$v" > /tmp/make.log 2>&1 || { echo "BUILD FAILED: $v"; tail -5 /tmp/make.log; exit 1; }
   cp ../libpsk_soft_hip.so /tmp/lib_variant_$i.so
   i=$((i+1))
@@ -23,4 +23,4 @@ print('RUN $i ms_per_step %.4f launch %.4f check %s' % (d['ms_per_step'], d['roo
   done
 done
 cp /tmp/lib_orig.so $R/psk_soft_amd/libpsk_soft_hip.so
-rm -f $R/psk_soft_amd/csrc/obj/psk_fast_S8_H1_E0.o
+rm -f $R/psk_soft_amd/csrc/obj/${OBJ:-psk_fast_S8_H1_E0}.o
