@@ -219,8 +219,8 @@ constexpr uint32_t kTiledFewChannels = 64, kTiledMinBlocksFew = 16, kTiledMaxCha
 constexpr uint64_t kTiledTargetTiles = 4096;
 // the pipelined mode of the time-tiled path (front / fit / back of consecutive ranges of tiles on three streams, psk_tile.hip:
 // psk_tile_fit_range_kernel): window classes of a few hundred to a few thousand channels with long calls
-constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 1280, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
-constexpr size_t kPipeMaxSymbols = (size_t)1 << 27;  // (52 bytes of scratch a symbol)
+constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 1408, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
+constexpr size_t kPipeMaxSymbols = (size_t)1 << 29;  // (16 bytes of scratch a symbol: 8 GiB)
 constexpr int kPipeEvents = 2 * (int)kPipeMaxRanges + 2;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
@@ -296,6 +296,7 @@ struct psk_soft_handle {
     float *d_traw = nullptr, *d_test = nullptr;
     float2 *d_ts = nullptr;
     size_t tile_cap = 0, tile_sym_cap = 0;
+    size_t pf_cap = 0, pf_sym_cap = 0;  // ... of the parallel fit's arrays (the classes that use it come first in the scratch)
     psk::PfScratch pf{};   // ... and of the parallel fit (psk_pfit.h), same capacities; PfChan: one per channel of the handle
     int opt_pfit = 1;      // PSK_SOFT_PARALLEL_FIT (environment): 0 = time-tiled calls keep the block-by-block fit (A/B runs),
                            // 2 = the second round of the parallel fit is always enqueued (tests), 1 = for a while after
@@ -924,7 +925,10 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     bool piped_SH[33][17] = {};
     uint32_t pipe_tiles_SH[33][17] = {};  // tiles of a range
     size_t pipe_need = 0;
-    if (h->opt_tiled) {
+    // (the parallel fit's scratch, 36 of the 52 bytes a symbol, is only needed by the classes that are not pipelined: those get
+    // their places first, so that it need not cover the others)
+    size_t pf_syms = tile_syms, pf_count = tile_count;
+    for (int pass = 0; pass < (h->opt_tiled ? 2 : 0); pass++) {
         for (int S : kFastS)
             for (int H : kClassH) {
                 if (!res.need_SH[S][H] || !psk::tile_front_has(S, class_H(H)))
@@ -935,6 +939,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                                                     : h->opt_pipe && h->opt_tiled == 1 && res.cnt_SH[S][H] >= kPipeMinChannels &&
                                                           res.cnt_SH[S][H] <= kPipeMaxChannels && res.max_blocks_SH[S][H] >= kPipeMinBlocks) &&
                                   !cont && res.max_n[S][H] + 128u <= kPipeMaxYLen && (size_t)res.blocks_SH[S][H] * 128u <= kPipeMaxSymbols;
+                if (pipe != (pass == 1))
+                    continue;
                 if (!pipe && h->opt_tiled == 1 &&
                     !((res.cnt_SH[S][H] <= kTiledFewChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocksFew) ||
                       (res.cnt_SH[S][H] <= kTiledMaxChannels && res.max_blocks_SH[S][H] >= kTiledMinBlocks)))
@@ -971,9 +977,11 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                     tile_syms += (size_t)nb * 128u;
                 }
             }
+        if (pass == 0)
+            pf_syms = tile_syms, pf_count = tile_count;
     }
     if (tile_syms) {
-        if (tile_syms > h->tile_sym_cap || tile_count > h->tile_cap) {
+        if (tile_syms > h->tile_sym_cap || tile_count > h->tile_cap || pf_syms > h->pf_sym_cap || pf_count > h->pf_cap) {
             // (rare: the scratch grows to the largest call seen, plus a quarter)
             PSK_HIP(hipDeviceSynchronize());
             if (h->d_tiles) (void)hipFree(h->d_tiles);
@@ -986,16 +994,17 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             h->d_tiles = nullptr, h->d_traw = h->d_test = nullptr, h->d_ts = nullptr;
             h->pf.k = nullptr, h->pf.y = nullptr, h->pf.S = h->pf.c = h->pf.xs = nullptr, h->pf.tt = nullptr, h->pf.tile = nullptr,
             h->pf.blk = nullptr, h->pf.walk = nullptr;
-            h->tile_cap = h->tile_sym_cap = 0;
+            h->tile_cap = h->tile_sym_cap = h->pf_cap = h->pf_sym_cap = 0;
             const size_t syms = tile_syms + tile_syms / 4, cnt = tile_count + tile_count / 4;
+            const size_t psyms = pf_syms + pf_syms / 4 + 128u, pcnt = pf_count + pf_count / 4 + 1u;
             // (out of device memory: the call does without -- the wave-scan kernels carry everything on their own)
             auto grab = [](auto **q, size_t bytes) { return hipMalloc((void **)q, bytes) == hipSuccess; };
             bool got = grab(&h->d_tiles, sizeof(psk::TileInfo) * cnt) && grab(&h->d_traw, sizeof(float) * syms) &&
                        grab(&h->d_test, sizeof(float) * syms) && grab(&h->d_ts, sizeof(float2) * syms) &&
-                       grab(&h->pf.k, sizeof(int) * syms) && grab(&h->pf.y, sizeof(float) * syms) && grab(&h->pf.S, sizeof(double) * syms) &&
-                       grab(&h->pf.c, sizeof(double) * syms) && grab(&h->pf.tt, sizeof(float) * syms) && grab(&h->pf.xs, sizeof(double) * syms) &&
-                       grab(&h->pf.tile, sizeof(psk::PfTile) * cnt) && grab(&h->pf.blk, sizeof(psk::PfBlock) * (syms / 128u + 1u)) &&
-                       grab(&h->pf.walk, sizeof(psk::PfWalk) * (syms / 128u + 1u));
+                       grab(&h->pf.k, sizeof(int) * psyms) && grab(&h->pf.y, sizeof(float) * psyms) && grab(&h->pf.S, sizeof(double) * psyms) &&
+                       grab(&h->pf.c, sizeof(double) * psyms) && grab(&h->pf.tt, sizeof(float) * psyms) && grab(&h->pf.xs, sizeof(double) * psyms) &&
+                       grab(&h->pf.tile, sizeof(psk::PfTile) * pcnt) && grab(&h->pf.blk, sizeof(psk::PfBlock) * (psyms / 128u + 1u)) &&
+                       grab(&h->pf.walk, sizeof(psk::PfWalk) * (psyms / 128u + 1u));
             if (got && !h->pf.chan) {
                 got = grab(&h->pf.chan, sizeof(psk::PfChan) * h->nch) && hipMemset(h->pf.chan, 0, sizeof(psk::PfChan) * h->nch) == hipSuccess &&
                       hipHostMalloc((void **)&h->pf.hint, 64) == hipSuccess;
@@ -1020,6 +1029,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             } else {
                 h->tile_cap = cnt;
                 h->tile_sym_cap = syms;
+                h->pf_cap = pcnt;
+                h->pf_sym_cap = psyms;
             }
         }
     }
