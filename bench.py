@@ -59,7 +59,7 @@ def parse():
                     help="skip the one-channel measurement (BASELINE configs[1]) that the default run appends as `few_channels`")
     ap.add_argument("--no-extra", dest="no_extra", action="store_true",
                     help="skip the other configurations the default single-GPU run appends to its line (`configs3_per_gpu`, `mixed`, "
-                         "`worst_case`, `few_channels_64` / `_512`, `end_to_end`), each measured like the headline with its own oracle check")
+                         "`worst_case`, `few_channels_64` / `_512` / `_1024`, `end_to_end`), each measured like the headline with its own oracle check")
     ap.add_argument("--strong", type=int, default=0, metavar="TOTAL_CHANNELS",
                     help="strong scaling: TOTAL_CHANNELS channels shared by the ranks (BASELINE configs[3]: "
                          "--M 8 --S 10 --strong 32768) instead of --channels per rank")
@@ -774,7 +774,7 @@ def main():
         wc["slowdown_vs_headline"] = wc["ms_per_step"] / dev_ms_avg
         res["worst_case"] = wc
         if not a.no_few:
-            for cf in (64, 512):
+            for cf in (64, 512, 1024):
                 res["few_channels_%d" % cf] = few_channels(pl, torch, dev, dev_index, M, S, a.numAvg, a.phaseAvg, a.check, C=cf,
                                                            modes=((1, "time_tiled"),))
         res["end_to_end"] = end_to_end(pl, torch, dev, dev_index)
