@@ -59,6 +59,10 @@ namespace {
 
 thread_local std::string g_last_error;
 thread_local bool g_long_call = false;  // process_round's note to psk_soft_process_device: plan the call in pieces
+// ... and: the batch mixes window classes that cannot be resident together -- cut every channel's call into g_split_pieces pieces in
+// time and let the classes run through them on their own streams, joined once at the end of the call (see process_device)
+thread_local int g_split_pieces = 0;
+thread_local bool g_split_mode = false;  // the rounds of such a call: their side streams are not joined in between
 
 psk_soft_status fail(psk_soft_status st, const std::string &msg)
 {
@@ -222,6 +226,8 @@ constexpr uint64_t kTiledTargetTiles = 4096;
 constexpr uint32_t kPipeMinChannels = 288, kPipeMaxChannels = 1408, kPipeMinBlocks = 256, kPipeMaxRanges = 32, kPipeMaxYLen = 1024;
 constexpr size_t kPipeMaxSymbols = (size_t)1 << 29;  // (16 bytes of scratch a symbol: 8 GiB)
 constexpr int kPipeEvents = 2 * (int)kPipeMaxRanges + 2;
+// a batch of several window classes whose calls are at least this long is cut in time (psk_soft_process_device)
+constexpr uint32_t kSplitMinBlocks = 128;
 constexpr uint32_t kSeqMaxS = 1024;    // symbolEnergy[] of the reference-order kernel lives in LDS
 const int kFastS[] = {2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                       18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
@@ -302,6 +308,7 @@ struct psk_soft_handle {
                            // 2 = the second round of the parallel fit is always enqueued (tests), 1 = for a while after
                            // a call reported a first guess that failed (pf.hint, a word the kernels write into page-locked memory)
     int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
+    int opt_split = 2;                      // PSK_SOFT_SPLIT_CLASSES=n (environment): pieces a mixed batch's calls are cut into (0 / 1: never)
     int opt_pipe = 1;                       // PSK_SOFT_PIPELINED=0 (environment): never the pipelined mode (A/B runs)
     hipStream_t pipe_st[2] = {};            // its fit and back streams (the front stage stays on the class's stream)
     hipEvent_t pipe_ev[kPipeEvents] = {};
@@ -427,6 +434,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_SPLIT_CLASSES"))
+        h->opt_split = std::atoi(e) < 0 ? 0 : std::atoi(e) > 16 ? 16 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_PIPELINED"))
         h->opt_pipe = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_DEFERRED_JOIN"))  // (as psk_soft_set_option(PSK_SOFT_OPT_DEFERRED_JOIN))
@@ -798,6 +807,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             p.handed_over = handed_over;
             if (cont && (cont[i] & 2u))
                 p.lf_flags |= psk::PLAN_NO_WRAP;  // (more pieces of this call follow)
+            if (cont && (cont[i] & 4u))
+                p.lf_flags |= psk::PLAN_CARRY_DRIFT;  // (a piece cut where the reference does not rebuild its sums)
             account(p, r, 1u);
         }
     };
@@ -1091,7 +1102,24 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 cls[n_cls++] = Cls{S, kClassH[k]};
     const bool fork = n_cls > 1 && h->opt_fork;
     // deferred join (see psk_soft_handle::opt_deferred): only calls whose every channel runs on wave-scan launches
-    bool deferred = fork && h->opt_deferred && !cont && !tile_syms && !res.cnt_any && !res.any_seq;
+    bool deferred = fork && (h->opt_deferred || g_split_mode) && (!cont || g_split_mode) && !tile_syms && !res.cnt_any && !res.any_seq;
+    if (fork && !cont && !h->opt_deferred && h->opt_split > 1 && !tile_syms && !res.cnt_any && !res.any_seq) {
+        // Classes that cannot be resident together (a SIMD's registers hold four waves of the short windows or two of the long
+        // ones) take two rounds of waves, and a wave that starts late still needs the whole call's time at the lone-wave rate.
+        // Cut in time, the pieces of the short class that start late are short too, and the class runs its last pieces with the
+        // machine to itself: configs[4] 3.4 -> 2.6 ms for ONE joined call.  The pieces are continuations of the one
+        // serviceFunction() call (plan_call's `cont`), the bounds that count the reference's rounding since the call began carry
+        // over (PLAN_CARRY_DRIFT).  Nothing is committed or enqueued here: the caller plans the pieces.
+        uint32_t listed = res.cnt_quiet, longest = 0;
+        for (int i = 0; i < n_cls; i++) {
+            listed += res.cnt_SH[cls[i].S][cls[i].H];
+            longest = res.max_blocks_SH[cls[i].S][cls[i].H] > longest ? res.max_blocks_SH[cls[i].S][cls[i].H] : longest;
+        }
+        if (listed == nch && longest >= kSplitMinBlocks) {
+            g_split_pieces = h->opt_split;
+            return PSK_SOFT_OK;
+        }
+    }
     uint64_t sig = 1469598103934665603ull;
     if (deferred) {
         auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
@@ -1303,12 +1331,23 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     // (the ordinary call is planned as it is; the plan pass itself says when a channel's call is too long for one piece --
     // nothing is committed or enqueued then)
     g_long_call = false;
+    g_split_pieces = 0;
     {
         const psk_soft_status st = process_round(h, ch0, nch, pkts, outs, stream_v, nullptr);
-        if (st != PSK_SOFT_OK || !g_long_call)
+        if (st != PSK_SOFT_OK || (!g_long_call && g_split_pieces < 2))
             return st;
         g_long_call = false;
     }
+    // (a mixed batch cut in time, see process_round: every channel's call in `split` pieces of whole blocks; the side streams of
+    // the rounds are joined once, behind the last)
+    const uint64_t split = g_split_pieces > 1 ? (uint64_t)g_split_pieces : 0;
+    g_split_pieces = 0;
+    struct SplitScope {
+        bool on;
+        explicit SplitScope(bool v) : on(v) { g_split_mode = v; }
+        ~SplitScope() { g_split_mode = false; }
+    } split_scope(split != 0);
+    std::vector<uint64_t> piece_cap(split ? nch : 0, ~0ull);  // symbols a piece of the channel's call may emit
 
     // ---- pieces ----
     ctl_sync(h);
@@ -1327,7 +1366,7 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 q.sriChanged = 0;
                 q.inputQueueFlushed = 0;
             }
-            cont[i] = round > 0 ? 1 : 0;
+            cont[i] = round > 0 ? (split ? 5 : 1) : 0;  // (bit 2: the bounds of the call so far carry over, PLAN_CARRY_DRIFT)
             if (!q.present || q.sri_mode != 1) {
                 left[i] = 0;
                 continue;
@@ -1347,7 +1386,12 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
                 oo.cap_symbols = ~0ull;
                 if (psk::plan_call(probe, h->lim, qq, oo, pl, (cont[i] & 1u) != 0) != PSK_SOFT_OK)
                     break;  // (the real pass reports it)
-                const uint64_t lim_sym = psk::kResyncCount - pl.lf_count0 < psk::kResyncCount ? psk::kResyncCount - pl.lf_count0 : psk::kResyncCount;
+                uint64_t lim_sym = psk::kResyncCount - pl.lf_count0 < psk::kResyncCount ? psk::kResyncCount - pl.lf_count0 : psk::kResyncCount;
+                if (split) {
+                    if (round == 0 && attempt == 0)  // (the whole call's symbols: pieces of whole blocks, `split` of them)
+                        piece_cap[i] = ((oo.n_symbols + split - 1) / split + 127ull) & ~127ull;
+                    lim_sym = piece_cap[i] < lim_sym ? piece_cap[i] : lim_sym;
+                }
                 const bool last = n_fl == left[i];
                 if (oo.n_symbols <= lim_sym && (last || (oo.n_symbols & 1ull) == 0))
                     break;
@@ -1404,6 +1448,10 @@ psk_soft_status psk_soft_process_device(psk_soft_handle_t *h, uint32_t ch0, uint
     for (uint32_t i = 0; i < nch; i++) {
         outs[i] = total[i];
         h->last_mode[ch0 + i] = mode_of[i];
+    }
+    if (split && !h->dry && !h->opt_deferred) {  // (the call ends like any other: the caller's stream behind all of it)
+        PSK_HIP(hipSetDevice(h->device));
+        PSK_HIP(deferred_join(h, stream_v ? (hipStream_t)stream_v : h->stream));
     }
     return PSK_SOFT_OK;
 }

@@ -203,7 +203,13 @@ __global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PE
 
     // ---- the symbol loop ----
     if constexpr (SV != 0) {
-        fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy);
+        // (a later piece of a call cut in time starts from the largest window sum the earlier pieces met: PLAN_CARRY_DRIFT)
+        const float carried = (p.lf_flags & PLAN_CARRY_DRIFT) ? __uint_as_float(st->pad_state) : 0.0f;
+        fast_main_loop<SV, HV, EXACT>(p, X, yring, ymask, er, cy, 0, -1, nullptr, nullptr, carried >= 0.0f ? carried : __builtin_inff());
+        // (... and leaves its own for the piece behind it -- written here, not with the state: kept until the epilogue the value
+        // cost samplesPerBaud 10 five per cent; a call that is refused further down is redone by a kernel that writes it again)
+        if (lane == 0)
+            st->pad_state = __float_as_uint(cy.wmax * 1.00001f);
         if constexpr (PSK_PACE_ON(false, EXACT))
             pace_post(pace_key(), 0u, lane);  // (on every way out of the loop: nothing left, whoever takes this wave slot next)
     }

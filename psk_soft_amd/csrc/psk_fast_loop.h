@@ -1304,8 +1304,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
     float wmax_prev = 0.0f;
 #pragma unroll
     for (int k = 0; k < S; k++) wmax_prev = __builtin_fmaxf(wmax_prev, Wf[k]);
-    if constexpr (FRONT)  // (a tile starts from what the channel's last call says its window sums can reach: see ChanState::emax_hint)
-        wmax_prev = __builtin_fmaxf(wmax_prev, wmax_floor);
+    // (a tile starts from what the channel's last call says its window sums can reach: see ChanState::emax_hint; a piece of a
+    // call cut in time from the largest sum of the pieces before it: PLAN_CARRY_DRIFT; zero everywhere else)
+    wmax_prev = __builtin_fmaxf(wmax_prev, wmax_floor);
+    if constexpr (EXACT)
+        cy.wmax = __builtin_fmaxf(cy.wmax, wmax_floor);
     float err_c = 2.0f * kU * wmax_prev;
     // rounding-error budget of one screened block, relative to the largest window sum in play:
     // the local roundings of up to 2*(128/A+1) window-loads of energy pass through the scan, plus
@@ -1587,9 +1590,11 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                     const bool fail[kR] = {!ok0, !ok1};
                     const float best_f[kR] = {__int_as_float(m1[0]), __int_as_float(m1[1])};
                     const int second_k[kR] = {IMASK - (m2[0] & IMASK), IMASK - (m2[1] & IMASK)};
+                    // (symbols since the reference last rebuilt its sums: this call's, plus -- PLAN_CARRY_DRIFT -- the earlier pieces')
+                    const int sym0 = (p.lf_flags & PLAN_CARRY_DRIFT) ? (int)p.count0 : 0;
                     exact_block_from_ring<S, FRONT>(er, ring_base, A, lane, cy, bestK,
-                                                    2.0f * drift_bound(c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr,
-                                                    2.0f * drift_bound(c * kB + kB, A));
+                                                    2.0f * drift_bound(sym0 + c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr,
+                                                    2.0f * drift_bound(sym0 + c * kB + kB, A));
                     since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
                 } else {
@@ -1627,7 +1632,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                 const double b1 = (valid[1] && __builtin_fabs(top[1].best) < (double)__builtin_inff()) ? top[1].best : 0.0;
                 const float mx = (float)__builtin_fmax(b0, b1);
                 cy.wmax = __builtin_fmaxf(cy.wmax, wave_max_f32(__builtin_fmaxf(mx, 0.0f)) * 1.0000002f);
-                const float bound_abs = 2.0f * drift_bound(c * kB + kB, A) * cy.wmax;
+                const int sym0 = (p.lf_flags & PLAN_CARRY_DRIFT) ? (int)p.count0 : 0;
+                const float bound_abs = 2.0f * drift_bound(sym0 + c * kB + kB, A) * cy.wmax;
 #pragma unroll
                 for (int r = 0; r < kR; r++) {
                     bestK[r] = top[r].k;
@@ -1758,8 +1764,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
         if constexpr (H == 1)
             ring_base = er.wrap(ring_base + kB);
     }
-    if constexpr (FRONT && !EXACT)
-        cy.wmax = wmax_prev;
+    if constexpr (!EXACT)
+        cy.wmax = wmax_prev;  // (the largest window sum of the call, within the float shadow's bound: TileInfo::wmax, ChanState::pad_state)
 }
 
 #undef g_soft

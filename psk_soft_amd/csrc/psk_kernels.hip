@@ -304,6 +304,7 @@ __global__ __launch_bounds__(64) void psk_seq_kernel(const ChanPlan *__restrict_
         st->stat_exact = 0;
         st->stat_chain = 0;
         st->guard = redo ? 2u : 0u;  // 2 = "the guard sent this call here" (statistics)
+        st->pad_state = 0x7F800000u;  // (the largest window sum is not tracked here: a piece that continues this call assumes the worst)
         sh_head = head;
     }
     __syncthreads();

@@ -38,6 +38,11 @@ enum LfFlags : uint32_t {
     // a piece of a call the library has cut (more than 2^20 symbols: psk_capi.cpp) that is not the call's last: the end-of-call
     // wrap of the phase estimate (cpp/psk_soft.cpp:592-603) belongs to the end of the CALL
     PLAN_NO_WRAP = 32u,
+    // a piece of a call the library has cut where the reference does NOT rebuild its energy sums (psk_capi.cpp: the classes of a
+    // mixed batch in pieces): the rounding the reference's running sums have gathered since the call began -- ChanPlan::count0
+    // symbols ago, at the scale of the largest window sum met since, carried in ChanState::pad_state -- counts for the bounds
+    // of this piece too (drift_bound, psk_fast_loop.h)
+    PLAN_CARRY_DRIFT = 64u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582

@@ -462,6 +462,7 @@ PSK_DEV void pf_commit(const ChanPlan &p, uint32_t bi, uint32_t ch, ChanState *s
         cy.slope = is_fin(m_hint) ? m_hint : 0.0f;
     }
     cy.m = cy.b = 0.0f;
+    cy.wmax = __builtin_inff();  // (no piece of a call cut in time follows a time-tiled one: see PLAN_CARRY_DRIFT)
     cy.q = q_end;
     cy.last_k = ti[n_tiles - 1].last_k;
     cy.stat_blocks = (uint32_t)n_blocks;

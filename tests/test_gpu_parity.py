@@ -1287,3 +1287,61 @@ def test_deferred_join_of_mixed_window_classes(oracle_mod):
 
     for c in range(C):
         check(c)
+
+
+@pytest.mark.parametrize("pieces", [2, 3, 5])
+def test_mixed_batch_cut_in_time(oracle_mod, monkeypatch, pieces):
+    """A batch that mixes window classes with calls of 128 blocks or more is cut in time inside the library (psk_capi.cpp:
+    PSK_SOFT_SPLIT_CLASSES pieces, each a continuation of the ONE serviceFunction() call, the classes running through them on
+    their own streams and joined at the end of the call).  Cut points fall in the middle of the call, where the reference
+    neither rebuilds its energy sums nor resets its fit: everything -- timing picks, the unwrap across the cut, LinearFit's
+    sums and count, differential decoding's `last`, the end-of-call wrap (once, at the end) -- has to come out as in the uncut
+    call.  Two calls in a row, ragged lengths (a channel whose call is too short to cut, one that emits an odd number of
+    symbols), every channel against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from psk_soft_amd import lib as pl
+    from psk_soft_amd.stimulus import synth_channel
+
+    monkeypatch.setenv("PSK_SOFT_SPLIT_CLASSES", str(pieces))
+    S, C, calls = 8, 30, 2
+    Ms = [(2, 4, 8)[c % 3] for c in range(C)]
+    props = [dict(samplesPerBaud=S, constelationSize=Ms[c], numAvg=(25, 100, 200, 400, 1000)[c % 5], phaseAvg=(10, 50, 200)[(c // 5) % 3],
+                  differentialDecoding=int(c % 4 == 1)) for c in range(C)]
+    lens = [140000 + 8 * (37 * c % 1000) + (8 if c % 2 else 0) for c in range(C)]
+    lens[3], lens[4] = 9000, 70000  # (too short to cut; cut into fewer blocks than pieces x 128)
+    with ThreadPoolExecutor(8) as ex:
+        host = list(ex.map(lambda c: synth_channel(4200 + c, Ms[c], S, calls * lens[c], cfo=(0.02 if c % 7 == 0 else None)), range(C)))
+    h = pl.Handle(C, device=0, max_window_samples=16384, max_phase_avg=512)
+    h.configure(0, props)
+    cap = [lens[c] // S + 2 for c in range(C)]
+    d_in = [h.device_alloc(2 * lens[c] * 4) for c in range(C)]
+    d_soft, d_phase = [h.device_alloc(cap[c] * 8) for c in range(C)], [h.device_alloc(cap[c] * 4) for c in range(C)]
+    d_sidx, d_bits = [h.device_alloc(cap[c] * 2 + 4) for c in range(C)], [h.device_alloc(cap[c] * 6 + 4) for c in range(C)]
+    got = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
+    try:
+        for k in range(calls):
+            pk, out = (pl.Packet * C)(), (pl.Output * C)()
+            for c in range(C):
+                h.upload(d_in[c], host[c][2 * k * lens[c] : 2 * (k + 1) * lens[c]])
+                pk[c].data, pk[c].n_floats, pk[c].sri_xdelta, pk[c].sri_mode, pk[c].sriChanged, pk[c].present = d_in[c], 2 * lens[c], 0.01, 1, int(k == 0), 1
+                out[c].soft, out[c].bits, out[c].phase, out[c].sampleIndex, out[c].cap_symbols = d_soft[c], d_bits[c], d_phase[c], d_sidx[c], cap[c]
+            h.process_device(0, pk, out)
+            h.synchronize()
+            st = h.stats()
+            assert st["channels_fast"] == C and st["channels_sequential"] == 0, st
+            for c in range(C):
+                ns, b = int(out[c].n_symbols), {2: 1, 4: 2, 8: 3}[Ms[c]]
+                assert int(out[c].n_bits) == b * ns and int(out[c].n_sampleIndex) == ns
+                got[c]["soft"].append(h.download(d_soft[c], (2 * ns,), np.float32))
+                got[c]["phase"].append(h.download(d_phase[c], (ns,), np.float32))
+                got[c]["index"].append(h.download(d_sidx[c], (ns,), np.int16))
+                got[c]["bits"].append(h.download(d_bits[c], (b * ns,), np.int16))
+    finally:
+        for lst in (d_in, d_soft, d_phase, d_sidx, d_bits):
+            for q in lst:
+                h.device_free(q)
+        h.close()
+    for c in range(C):
+        ref = oracle_run(oracle_mod, host[c], props[c], packet=lens[c])
+        assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, ref, "cut in %d, channel %d (%s)" % (pieces, c, props[c]))
