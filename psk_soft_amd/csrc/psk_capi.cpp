@@ -1115,7 +1115,11 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             listed += res.cnt_SH[cls[i].S][cls[i].H];
             longest = res.max_blocks_SH[cls[i].S][cls[i].H] > longest ? res.max_blocks_SH[cls[i].S][cls[i].H] : longest;
         }
-        if (listed == nch && longest >= kSplitMinBlocks) {
+        static const uint32_t min_blocks = [] {  // (PSK_SOFT_SPLIT_MIN_BLOCKS: tests cut short calls too)
+            const char *e = std::getenv("PSK_SOFT_SPLIT_MIN_BLOCKS");
+            return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : kSplitMinBlocks;
+        }();
+        if (listed == nch && longest >= min_blocks) {
             g_split_pieces = h->opt_split;
             return PSK_SOFT_OK;
         }
