@@ -61,17 +61,17 @@ def lint(path, max_sites):
             if m:
                 carriers.add(m.group(1))
             # ---- EXEC bookkeeping ----
-            m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\])", t)
+            m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\]|vcc)", t)
             if m:
                 stack.append((m.group(1), region))
                 region = next_region
                 next_region += 1
                 continue
-            m = re.match(r"s_or_saveexec_b64 (s\[\d+:\d+\]), -1", t)
+            m = re.match(r"s_or_saveexec_b64 (s\[\d+:\d+\]|vcc), -1", t)
             if m:
                 wwm = m.group(1)
                 continue
-            m = re.match(r"s_(or|mov)_b64 exec, (?:exec, )?(s\[\d+:\d+\])", t)
+            m = re.match(r"s_(or|mov)_b64 exec, (?:exec, )?(s\[\d+:\d+\]|vcc)", t)
             if m:
                 if wwm and m.group(2) == wwm:
                     wwm = None

@@ -10,8 +10,10 @@ for s in $(seq 2 16); do for e in 0 1; do list="$list $s,8,$e"; done; done
 one() { IFS=, read s h e <<< "$1"; extra=""; 
   if [ $e = 1 ] && { [ $h = 8 ] || { [ $s -ge 17 ] && [ $h -ge 2 ]; } || { [ $s -ge 11 ] && [ $h = 4 ]; }; }; then extra="-mllvm -amdgpu-spill-sgpr-to-vgpr=0"; fi
   tools/isa_dump.sh $s $h $e $2/k_${s}_${h}_${e}.s $extra > /dev/null 2>&1
-  python3 tools/isa_exec_spills.py $2/k_${s}_${h}_${e}.s --sites 0 | sed "s/^k_/S,H,E = /"; rm -f $2/k_${s}_${h}_${e}.s; }
+  python3 tools/isa_exec_spills.py $2/k_${s}_${h}_${e}.s --sites 0 | sed "s/^k_/S,H,E = /"
+  python3 tools/isa_lane_loss.py $2/k_${s}_${h}_${e}.s --sites 3 | sed "s/^k_/LANES S,H,E = /" >> $2/lanes.txt; rm -f $2/k_${s}_${h}_${e}.s; }
 export -f one
 echo $list | tr ' ' '\n' | grep . | xargs -P 8 -I{} bash -c "one {} $tmp" > $out.unsorted
-sort -t_ -k2,2n -k3,3n -k4,4n $out.unsorted > $out; rm -f $out.unsorted; rmdir $tmp
+sort -t_ -k2,2n -k3,3n -k4,4n $out.unsorted > $out; rm -f $out.unsorted; cp $tmp/lanes.txt $out.lanes; rm -f $tmp/lanes.txt; rmdir $tmp
+echo "instantiations with D sites / with E sites (tools/isa_lane_loss.py):"; grep -c "no covering save) [1-9]" $out.lanes; grep -c "mask restore) [1-9]" $out.lanes
 grep -c . $out; grep -v "C (lane carrier moved under a partial mask) 0" $out | wc -l
