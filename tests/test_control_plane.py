@@ -276,6 +276,9 @@ def test_options_and_pinned_allocation_without_gpu():
     h = pl.Handle(1, device=pl.DEVICE_NONE) if hasattr(pl, "DEVICE_NONE") else pl.Handle(1, device=-1)
     h.set_option(h.OPT_QPSK_SIGN_BITMAP, 1)
     h.set_option(h.OPT_QPSK_SIGN_BITMAP, 0)
+    h.set_option(h.OPT_DEFERRED_JOIN, 1)  # (a control-plane-only handle has no streams: the option is kept, join is a no-op)
+    h.join()
+    h.set_option(h.OPT_DEFERRED_JOIN, 0)
     with pytest.raises(pl.PskSoftError) as e:
         h.set_option(12345, 1)
     assert e.value.status == 1  # PSK_SOFT_ERR_INVALID_ARG
