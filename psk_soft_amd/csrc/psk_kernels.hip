@@ -328,7 +328,9 @@ namespace psk {
 // (numAvg <= 128: the screened kernel settles near-ties itself; its exact-timing sibling takes the calls with
 // non-finite samples or a non-finite / astronomically large phase estimate in the channel state)
 #define PSK_DECL_S(S) PSK_DECL_SH(S, 1) PSK_DECL_SH(S, 2) PSK_DECL_SH(S, 4)
-PSK_DECL(8, 0, 0)
+// (H = 0: the screened tier without window history in registers, psk_fast_loop.h REREAD -- the launches of the numAvg 513 ... 1024 class)
+PSK_DECL(2, 0, 0) PSK_DECL(3, 0, 0) PSK_DECL(4, 0, 0) PSK_DECL(5, 0, 0) PSK_DECL(6, 0, 0) PSK_DECL(7, 0, 0) PSK_DECL(8, 0, 0) PSK_DECL(9, 0, 0)
+PSK_DECL(10, 0, 0) PSK_DECL(11, 0, 0) PSK_DECL(12, 0, 0) PSK_DECL(13, 0, 0) PSK_DECL(14, 0, 0) PSK_DECL(15, 0, 0) PSK_DECL(16, 0, 0)
 PSK_DECL_S(2)
 PSK_DECL_S(3)
 PSK_DECL_S(4)
@@ -385,9 +387,20 @@ hipError_t launch_fast(int S, int H, int exact, PSK_FAST_ARGS)
     if (S == 0)
         return launch_fast_inst<0, 1, false>(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
     {
-        static const bool reread = [] { const char *e = getenv("PSK_SOFT_REREAD"); return e && e[0] == '1'; }();
-        if (reread && !exact && H > 1 && S == 8)
-            return launch_fast_S8_H0_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+        // Windows of 513 ... 1024 symbols: eight blocks of history in registers are 430 ... 480 VGPRs, one wave to a SIMD; the variant
+        // that reads the symbols leaving the window a second time instead (H == 0) keeps four -- twice the loads, and still a
+        // quarter faster at every batch size measured (4096 channels, numAvg 600: 6.37 -> 4.80 ms; 2048: 3.24 -> 2.16; 256: 1.72
+        // -> 1.55).  For the shorter windows (two / four blocks, two waves to a SIMD) the registers win.  PSK_SOFT_REREAD
+        // (environment): 0 never, 1 the eight-block class (default), 2 every window longer than a block.
+        static const int reread = [] { const char *e = getenv("PSK_SOFT_REREAD"); return e ? atoi(e) : 1; }();
+        if (!exact && S >= 2 && S <= 16 && ((reread >= 1 && H == 8) || (reread >= 2 && H > 1))) {
+#define PSK_CASE0(Sv) \
+    if (S == Sv)      \
+        return launch_fast_S##Sv##_H0_E0(plans, list, ch0, nch, states, rings, ring_cap, yvs, fit_cap, y_len, r_len, stream);
+            PSK_CASE0(2) PSK_CASE0(3) PSK_CASE0(4) PSK_CASE0(5) PSK_CASE0(6) PSK_CASE0(7) PSK_CASE0(8) PSK_CASE0(9) PSK_CASE0(10)
+            PSK_CASE0(11) PSK_CASE0(12) PSK_CASE0(13) PSK_CASE0(14) PSK_CASE0(15) PSK_CASE0(16)
+#undef PSK_CASE0
+        }
     }
 #define PSK_CASE(Sv, Hv)                                                                                              \
     if (S == Sv && H == Hv)                                                                                           \
