@@ -308,6 +308,7 @@ struct psk_soft_handle {
                            // 2 = the second round of the parallel fit is always enqueued (tests), 1 = for a while after
                            // a call reported a first guess that failed (pf.hint, a word the kernels write into page-locked memory)
     int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
+    int opt_ties_in_place = 1;              // PSK_SOFT_TIES_IN_PLACE=0 (environment): PLAN_TIES_HANDOVER in every plan (tests, A/B runs)
     int opt_split = 2;                      // PSK_SOFT_SPLIT_CLASSES=n (environment): pieces a mixed batch's calls are cut into (0 / 1: never)
     int opt_pipe = 1;                       // PSK_SOFT_PIPELINED=0 (environment): never the pipelined mode (A/B runs)
     hipStream_t pipe_st[2] = {};            // its fit and back streams (the front stage stays on the class's stream)
@@ -434,6 +435,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
     h->dry = (device == PSK_SOFT_DEVICE_NONE);
     if (const char *e = std::getenv("PSK_SOFT_TIME_TILED"))
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_TIES_IN_PLACE"))
+        h->opt_ties_in_place = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_SPLIT_CLASSES"))
         h->opt_split = std::atoi(e) < 0 ? 0 : std::atoi(e) > 16 ? 16 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_PIPELINED"))
@@ -653,7 +656,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
     }
     // plan on copies (ctl_next); commit only if every channel of the batch is accepted
     const bool dry = h->dry;
-    const uint32_t extra_flags = h->opt_qpsk_sign_map ? (uint32_t)psk::PLAN_QPSK_SIGN_MAP : 0u;
+    const uint32_t extra_flags = (h->opt_qpsk_sign_map ? (uint32_t)psk::PLAN_QPSK_SIGN_MAP : 0u) |
+                                 (h->opt_ties_in_place ? 0u : (uint32_t)psk::PLAN_TIES_HANDOVER);
     const psk::Limits lim = h->lim;
     // what a planned channel asks of the launches (`mult` channels with this very plan)
     auto account = [&](const psk::ChanPlan &p, PlanSummary &r, uint32_t mult) {

@@ -133,11 +133,16 @@ PSK_DEV void call_epilogue(const ChanPlan &p, ChanState *st, float *yv, uint32_t
 // themselves, a hair over the 168 that let three waves share a SIMD instead of two -- and held to 168 they fit without a
 // spill.  Measured SLOWER on a machine-filling batch (4096 channels, numAvg 200: 3.60 against 3.06 ms): 3072 waves and then
 // 1024 is a full round and a third of one, two rounds of 2048 are two full ones.  Left at 1 (the compiler's own count).
+// (no window history in registers, H == 0: see psk_fast_loop.h REREAD; samplesPerBaud <= 5 is bound by arithmetic and keeps four
+// waves: samplesPerBaud 2 / 4 at two waves measured 12.0 / 6.8 ms against 6.9 / 4.4)
+#ifndef PSK_WAVES_PER_SIMD_H0
+#define PSK_WAVES_PER_SIMD_H0 2  /* (170 registers, nothing spilled, two full rounds of 2048 waves: numAvg 600 4.3 ms; 3: 5.9 -- a round and a third --; 4: 5.1, 37 registers spilled) */
+#endif
 #ifndef PSK_WAVES_PER_SIMD_H2
 #define PSK_WAVES_PER_SIMD_H2 1
 #endif
 template <int SV, int HV, bool EXACT>
-__global__ __launch_bounds__(64, ((HV <= 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : (HV == 2 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD_H2 : (HV == 4 && SV <= 8 && !EXACT && PSK_DBUF) ? 2 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
+__global__ __launch_bounds__(64, ((HV == 0 && SV <= 5 && !EXACT) ? 4 : (HV == 0 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD_H0 : (HV == 1 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD : (HV == 2 && SV <= 10 && !EXACT) ? PSK_WAVES_PER_SIMD_H2 : (HV == 4 && SV <= 8 && !EXACT && PSK_DBUF) ? 2 : 1)) void psk_fast_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
                                                       ChanState *__restrict__ states, float2 *__restrict__ rings,
                                                       uint32_t ring_cap, float *__restrict__ yvs, uint32_t fit_cap,
                                                       uint32_t y_len, uint32_t r_len)

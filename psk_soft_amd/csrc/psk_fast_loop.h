@@ -48,6 +48,9 @@ namespace psk {
 constexpr int kR = 2;           // symbols per lane per block
 constexpr int kB = kWave * kR;  // symbols per block
 constexpr int kMaxUnwrapPasses = 160;
+#ifndef PSK_TIES_IN_PLACE
+#define PSK_TIES_IN_PLACE 1
+#endif
 #ifndef PSK_WIDE_FIRST
 #define PSK_WIDE_FIRST 1
 #endif
@@ -826,6 +829,55 @@ PSK_DEV void window_end_reread_f32(const XView &X, int c, int c_begin, uint32_t 
     for (int k = 0; k < S; k++) W[k] = read_lane(wave_scan_f32(acc[k]), 63);
 }
 
+// EXACT window sums at the last position of the newest kept block, for the in-place redo of a block in the screened tier of the
+// windows longer than a block: float-valued energies added in double (exact under the exponent-spread guard, which is fed
+// with every energy that enters here), from the history in registers ...
+template <int S, int H>
+PSK_DEV void window_end_f64(const BlockKeep<S> (&hist)[H], uint32_t A, int lane, FastCarry &cy, double (&W)[S])
+{
+    const int u = (int)((A - 1) / kB), v = (int)A - u * kB;  // 1 <= v <= kB
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = H - 1; j >= 0; j--) {  // (oldest block first, like the call's prologue)
+            const bool whole = j < u, part = j == u;
+#pragma unroll
+            for (int r = 0; r < kR; r++)
+                if (whole || (part && 2 * lane + r >= kB - v)) {
+                    guard_track<true>(cy, hist[j].e[r][k]);
+                    acc += (double)hist[j].e[r][k];
+                }
+        }
+        W[k] = wave_sum_f64(acc);
+    }
+}
+// ... or, without a history (H == 0), from the window's symbols read again: the A symbols that end with block c_end's last
+template <int S>
+PSK_DEV void window_end_reread_f64(const XView &X, int c_end, int c_begin, uint32_t A, long long tau_last, int lane, FastCarry &cy, double (&W)[S])
+{
+    const int u = (int)((A - 1) / kB), v = (int)A - u * kB;
+    double acc[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) acc[k] = 0.0;
+    for (int j = u; j >= 0; j--) {
+        float2 x[kR][S];
+        load_block<S>(X, (long long)(c_end - j), A, (long long)c_begin * kB, tau_last, lane, x);
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            const bool in = j < u || 2 * lane + r >= kB - v;
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                const float e = in ? norm_f(x[r][k].x, x[r][k].y) : 0.0f;
+                guard_track<true>(cy, e);  // (zero: neutral)
+                acc[k] += (double)e;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < S; k++) W[k] = wave_sum_f64(acc[k]);
+}
+
 // the same for numAvg <= 128 from the LDS ring: the window is the positions >= kB - A of the block
 // at `base`
 template <bool DYN>
@@ -1595,6 +1647,43 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                     exact_block_from_ring<S, FRONT>(er, ring_base, A, lane, cy, bestK,
                                                     2.0f * drift_bound(sym0 + c * kB + kB, A) * wmax_prev, fail, best_f, second_k, thr,
                                                     2.0f * drift_bound(sym0 + c * kB + kB, A));
+                    since_refresh = kScreenRefresh;
+                    cy.stat_exact_blocks += 1;
+                } else if (PSK_TIES_IN_PLACE && !(p.lf_flags & PLAN_TIES_HANDOVER)) {
+                    // windows longer than a block: this block settled exactly too, here -- the exact tier's pass over it (float-valued
+                    // addends in double, the reference's first-maximum rule, the ambiguity left to the guard at the end of the kernel),
+                    // started from window sums rebuilt from the history.  (Handing the whole call to the exact tier instead -- one or
+                    // two waves to a SIMD -- cost a noisy batch of numAvg 400 80 % and 8-PSK at 10 samples per baud 160 %.)
+                    double Wst[S];
+                    if constexpr (REREAD)
+                        window_end_reread_f64<S>(X, c - 1, c_begin, A, tau_last, lane, cy, Wst);
+                    else
+                        window_end_f64<S, H>(hist, A, lane, cy, Wst);
+                    ArgTop top[kR];
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        guard_track<true>(cy, cur.e[0][k]);
+                        guard_track<true>(cy, cur.e[1][k]);
+                        const double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
+                        const double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
+                        const double incl = wave_scan_f64(d0 + d1);
+                        const double W1 = Wst[k] + incl;
+                        const double W0 = (Wst[k] + wave_up1(incl, 0.0)) + d0;
+                        if (k == 0) {
+                            argtop_first(top[0], W0);
+                            argtop_first(top[1], W1);
+                        } else {
+                            argtop_next(top[0], W0, k);
+                            argtop_next(top[1], W1, k);
+                        }
+                    }
+                    const int sym0 = (p.lf_flags & PLAN_CARRY_DRIFT) ? (int)p.count0 : 0;
+                    const float bound_abs = 2.0f * drift_bound(sym0 + c * kB + kB, A) * wmax_prev * 1.00001f;
+#pragma unroll
+                    for (int r = 0; r < kR; r++) {
+                        bestK[r] = top[r].k;
+                        cy.ambiguous = cy.ambiguous || (valid[r] && argtop_ambiguous(top[r], bound_abs));
+                    }
                     since_refresh = kScreenRefresh;
                     cy.stat_exact_blocks += 1;
                 } else {

@@ -43,6 +43,9 @@ enum LfFlags : uint32_t {
     // symbols ago, at the scale of the largest window sum met since, carried in ChanState::pad_state -- counts for the bounds
     // of this piece too (drift_bound, psk_fast_loop.h)
     PLAN_CARRY_DRIFT = 64u,
+    // (tests, A/B runs: PSK_SOFT_TIES_IN_PLACE=0) windows longer than a block hand a call with a near-tie to the exact tier, as
+    // before round 3, instead of settling the block in place
+    PLAN_TIES_HANDOVER = 128u,
 };
 
 constexpr uint32_t kResyncCount = 1048576u;  // cpp/psk_soft.cpp:51, 582

@@ -186,17 +186,17 @@ def test_edge_packets(oracle_mod):
 
 def test_tie_heavy_signal_takes_the_exact_timing_path(oracle_mod):
     """Rectangular pulses (the reference test's own stimulus): every intra-symbol phase has the
-    same energy up to noise, the float screening cannot vouch for the argmax.  For numAvg <= 128
-    the screened kernel settles such blocks itself, exactly, from its energy ring; for larger
-    windows it hands the call to the exact-timing kernel (an in-place redo from the register
-    history was measured to cost 8-13 % of the steady state of those instantiations).  Either way
-    the first-maximum tie rule has to match the reference."""
+    same energy up to noise, the float screening cannot vouch for the argmax.  The screened kernel
+    settles such blocks itself, exactly: from its energy ring for numAvg <= 128, from the register
+    history (or, numAvg > 512, from the window's samples read again) for larger windows -- round 3;
+    before, those handed the whole call to the exact-timing kernel, which cost a noisy batch of numAvg
+    400 80 %.  Either way the first-maximum tie rule has to match the reference."""
     import random as _random
 
     from ref_stimulus import gen_psk
 
     data, _ = gen_psk(3000, samp_per_baud=8, num_syms=4, differential=False, rng=_random.Random(11))
-    for numAvg, in_kernel in ((100, True), (200, False)):
+    for numAvg, in_kernel in ((100, True), (200, True), (400, True), (600, True)):
         props = dict(samplesPerBaud=8, constelationSize=4, numAvg=numAvg)
         ref = oracle_run(oracle_mod, data, props, packet=8192)
         h = _handle()
@@ -386,15 +386,19 @@ def test_long_phase_averages_stay_on_the_wave_scan_kernel(oracle_mod):
     h.close()
 
 
-def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod):
+@pytest.mark.parametrize("ties_in_place", [0, 1])
+def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod, monkeypatch, ties_in_place):
     """A case the randomised comparison found (tools/fuzz_gpu.py seed 1002, round 5, channel 194; the
     signal is tests/golden/cases/s11_a257_tail.npy, made by that tool's generator): samplesPerBaud 11,
     numAvg 257, near-ties that send both calls through the exact-timing instantiation <11, 4, true>
     (304 VGPRs), the second call ending in a partial block of 84 symbols.  An experimental build (a loop
     added to fit_block that was never executed) wrote garbage soft symbols for exactly those 84; the
-    committed code is right, and this keeps it so."""
+    committed code is right, and this keeps it so.  (Since round 3 the screened kernel settles such near-ties in place and the
+    call no longer reaches the exact tier: ties_in_place = 0 -- PSK_SOFT_TIES_IN_PLACE=0 -- keeps the case on <11, 4, true>,
+    ties_in_place = 1 runs it the way it runs now.)"""
     import os
 
+    monkeypatch.setenv("PSK_SOFT_TIES_IN_PLACE", str(ties_in_place))
     sig = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases", "s11_a257_tail.npy"))
     props = dict(samplesPerBaud=11, constelationSize=4, numAvg=257, phaseAvg=385, differentialDecoding=0)
     cuts = [0, 35342, 132000]
@@ -407,7 +411,7 @@ def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod):
         d = sig[2 * cuts[k] : 2 * cuts[k + 1]]
         g = h.process_host(0, [dict(data=d, xdelta=0.01, sriChanged=(k == 0))])[0]
         st = h.stats()
-        assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
+        assert st["channels_exact_timing"] == 1 - ties_in_place and st["channels_sequential"] == 0, st
         r = o.service(d, 0.01, sriChanged=(k == 0))
         assert r.phase.size % 128 != 0
         assert_parity(g, dict(soft=r.soft, bits=r.bits, phase=r.phase, index=r.index), "call %d" % k)
@@ -415,16 +419,19 @@ def test_partial_last_block_through_the_exact_timing_kernel_s11(oracle_mod):
     h.close()
 
 
-def test_partial_last_block_wide_symbols_s30(oracle_mod):
+@pytest.mark.parametrize("ties_in_place", [0, 1])
+def test_partial_last_block_wide_symbols_s30(oracle_mod, monkeypatch, ties_in_place):
     """Two cases of the randomised comparison (tools/fuzz_gpu.py seed 20261004, rounds 129 and 148: channels 154 and
     18; the fixtures are the tails of their streams): samplesPerBaud 30, numAvg 400, a rectangular pulse in noise -- the
     30 timing phases within 1e-4 of each other, so the exact-timing instantiation <30, 4, true> (512 registers, 1431
     spills) decides; the call ends in a partial block.  The build of the time picked phase 9 where 13 had the larger
     sum by 5e-4, at three positions of that block: one sample of a symbol read as zero.  Its load path let every lane
     choose its own branch (packet / carried samples / nothing wanted); load_block now has none of that
-    (psk_fast_loop.h), and the wrong tail block of round 1 had the same signature."""
+    (psk_fast_loop.h), and the wrong tail block of round 1 had the same signature (DESIGN.md section 4 names the mechanism).
+    ties_in_place = 0 keeps the cases on <30, 4, true>; 1 is how they run since round 3: settled in place by <30, 4, false>."""
     import os
 
+    monkeypatch.setenv("PSK_SOFT_TIES_IN_PLACE", str(ties_in_place))
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cases")
     for name, M, n in (("s30_a400_tail_a.npy", 4, 1921), ("s30_a400_tail_b.npy", 8, 200)):
         sig = np.load(os.path.join(here, name))
@@ -435,7 +442,7 @@ def test_partial_last_block_wide_symbols_s30(oracle_mod):
         h.configure(0, [props])
         got = run_gpu(h, 0, sig, 0.01)
         st = h.stats()
-        assert st["channels_exact_timing"] == 1 and st["channels_sequential"] == 0, st
+        assert st["channels_exact_timing"] == 1 - ties_in_place and st["channels_sequential"] == 0, st
         assert_parity(got, ref, name)
         h.close()
 
