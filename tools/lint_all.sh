@@ -7,6 +7,7 @@ tmp=$(mktemp -d)
 list=""
 for s in $(seq 2 32); do for h in 1 2 4; do for e in 0 1; do list="$list $s,$h,$e"; done; done; done
 for s in $(seq 2 16); do for e in 0 1; do list="$list $s,8,$e"; done; done
+for s in $(seq 2 16); do list="$list $s,0,0"; done  # (H = 0: the screened variant without window history)
 one() { IFS=, read s h e <<< "$1"; extra=""; 
   if [ $e = 1 ] && { [ $h = 8 ] || { [ $s -ge 17 ] && [ $h -ge 2 ]; } || { [ $s -ge 11 ] && [ $h = 4 ]; }; }; then extra="-mllvm -amdgpu-spill-sgpr-to-vgpr=0"; fi
   tools/isa_dump.sh $s $h $e $2/k_${s}_${h}_${e}.s $extra > /dev/null 2>&1
