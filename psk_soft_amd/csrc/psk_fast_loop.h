@@ -831,7 +831,9 @@ PSK_DEV void window_end_reread_f32(const XView &X, int c, int c_begin, uint32_t 
 
 // EXACT window sums at the last position of the newest kept block, for the in-place redo of a block in the screened tier of the
 // windows longer than a block: float-valued energies added in double (exact under the exponent-spread guard, which is fed
-// with every energy that enters here), from the history in registers ...
+// with every energy that enters here; an energy that is not finite sets cy.refuse: the reference's RUNNING sums keep an inf
+// while it is in the window and are NaN from the moment it leaves, which only the exact tier's running sums reproduce),
+// from the history in registers ...
 template <int S, int H>
 PSK_DEV void window_end_f64(const BlockKeep<S> (&hist)[H], uint32_t A, int lane, FastCarry &cy, double (&W)[S])
 {
@@ -845,7 +847,7 @@ PSK_DEV void window_end_f64(const BlockKeep<S> (&hist)[H], uint32_t A, int lane,
 #pragma unroll
             for (int r = 0; r < kR; r++)
                 if (whole || (part && 2 * lane + r >= kB - v)) {
-                    guard_track<true>(cy, hist[j].e[r][k]);
+                    guard_track<false>(cy, hist[j].e[r][k]);
                     acc += (double)hist[j].e[r][k];
                 }
         }
@@ -869,7 +871,7 @@ PSK_DEV void window_end_reread_f64(const XView &X, int c_end, int c_begin, uint3
 #pragma unroll
             for (int k = 0; k < S; k++) {
                 const float e = in ? norm_f(x[r][k].x, x[r][k].y) : 0.0f;
-                guard_track<true>(cy, e);  // (zero: neutral)
+                guard_track<false>(cy, e);  // (zero: neutral; inf / NaN: the call is the exact tier's, whose sums run like the reference's)
                 acc[k] += (double)e;
             }
         }
@@ -1662,8 +1664,8 @@ PSK_DEV void fast_main_loop(const ChanPlan &p, const XView &X, float *yring, uin
                     ArgTop top[kR];
 #pragma unroll
                     for (int k = 0; k < S; k++) {
-                        guard_track<true>(cy, cur.e[0][k]);
-                        guard_track<true>(cy, cur.e[1][k]);
+                        guard_track<false>(cy, cur.e[0][k]);  // (an energy that is not finite: cy.refuse, as in the numAvg <= 128 redo)
+                        guard_track<false>(cy, cur.e[1][k]);
                         const double d0 = (double)cur.e[0][k] - (double)e_old[0][k];
                         const double d1 = (double)cur.e[1][k] - (double)e_old[1][k];
                         const double incl = wave_scan_f64(d0 + d1);
