@@ -1037,7 +1037,10 @@ PSK_DEV void fit_stage(int c, int lane, uint32_t n, float xd, float den_s, float
     float den_last = den_s, xavg_last = xavg_s;
     int pass, rejected = 0;
     float m_lane = 0.0f;  // (per lane) slope of the lane's last fit
-    const bool warm = !__builtin_expect(q0 >= n, 1);  // the fit window is still filling: the first phaseAvg symbols after a history clear
+    // the fit window is still filling: the first phaseAvg symbols after a history clear.  phaseAvg == 1 takes that path for good: a
+    // window of one point returns the point itself (cpp/psk_soft.cpp:164-171), whatever the sums have become -- after an infinite
+    // phase they are NaN (inf - inf at :70) and the steady-state formula, which goes through them, would return NaN from then on
+    const bool warm = !__builtin_expect(q0 >= n && n != 1u, 1);
     const bool cheap = cy.chain_run != 0;  // the recurrence ran on the last blocks: do not bother with candidates
     if (!warm) {
         pass = fit_block<false, EXACT>(lane, q0, n, xd, den_s, xavg_s, fk, valid, raw, cy, yring, ymask, y, est, ySum_l, xySum_l,

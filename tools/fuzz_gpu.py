@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pyoracle as po  # noqa: E402
 from psk_soft_amd import lib as pl  # noqa: E402
 
+NONFINITE = float(os.environ.get("PSK_FUZZ_NONFINITE", "0"))
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
@@ -56,6 +57,11 @@ def make_signal(rng, nrng, M, S, n):
     out = np.empty(2 * n, np.float32)
     out[0::2] = x.real
     out[1::2] = x.imag
+    # PSK_FUZZ_NONFINITE=p: with probability p a stream gets a few NaN / +-inf components (off by default: the streams of the
+    # seeds quoted in DESIGN.md stay what they were)
+    if NONFINITE and rng.random() < NONFINITE:
+        for _ in range(rng.randrange(1, 5)):
+            out[rng.randrange(0, 2 * n)] = rng.choice([np.float32("nan"), np.float32("inf"), -np.float32("inf")])
     return out
 
 
