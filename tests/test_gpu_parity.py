@@ -1364,3 +1364,32 @@ def test_mixed_batch_cut_in_time(oracle_mod, monkeypatch, pieces):
     for c in range(C):
         ref = oracle_run(oracle_mod, host[c], props[c], packet=lens[c])
         assert_parity({k: np.concatenate(v) for k, v in got[c].items()}, ref, "cut in %d, channel %d (%s)" % (pieces, c, props[c]))
+
+
+@pytest.mark.parametrize("scale", [1e-19, 1e-21, 3e-22, 2e-23])
+def test_energies_among_the_denormals(oracle_mod, scale):
+    """Samples of 1e-21: their energies, 1e-42, are denormal floats -- a fixed grid of 2^-149 on which the screening's RELATIVE
+    error bounds mean nothing and the phase index it writes into the low bits of a window sum moves the sum by several grid
+    steps.  The reference adds the same floats in double and picks the first maximum; the screened kernels have to notice that
+    they cannot tell and settle the block exactly (an absolute floor on the acceptance threshold, psk_fast_loop.h).  Found by
+    the randomised comparison at extreme amplitudes (tools/fuzz_gpu.py, PSK_FUZZ_EXTREME): wrong timing picks at 1e-21.  A
+    rectangular pulse in noise (every timing phase within the noise of the others), short and long windows, a 14-samples-per-
+    baud case like the one the comparison found; at 2e-23 most energies are 0 or 1 grid step."""
+    import random as _random
+
+    from psk_soft_amd.stimulus import synth_channel
+    from ref_stimulus import gen_psk
+
+    data, _ = gen_psk(3000, samp_per_baud=8, num_syms=4, differential=False, rng=_random.Random(12))
+    cases = [(np.asarray(data, np.float64), dict(samplesPerBaud=8, constelationSize=4, numAvg=100), 8192),
+             (np.asarray(data, np.float64), dict(samplesPerBaud=8, constelationSize=4, numAvg=300), 8192),
+             (synth_channel(77, 4, 14, 60000, sigma=0.05).astype(np.float64), dict(samplesPerBaud=14, constelationSize=4, numAvg=100, phaseAvg=400), 25000)]
+    for x, props, packet in cases:
+        iq = (x * scale).astype(np.float32)
+        ref = oracle_run(oracle_mod, iq, props, packet=packet)
+        h = _handle(1, max_phase_avg=512)
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, packet)
+        assert h.stats()["channels_sequential"] == 0
+        assert_parity(got, ref, "scale %g %s" % (scale, props))
+        h.close()

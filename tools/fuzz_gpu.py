@@ -17,6 +17,7 @@ from oracle import pyoracle as po  # noqa: E402
 from psk_soft_amd import lib as pl  # noqa: E402
 
 NONFINITE = float(os.environ.get("PSK_FUZZ_NONFINITE", "0"))
+EXTREME = float(os.environ.get("PSK_FUZZ_EXTREME", "0"))
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
@@ -45,6 +46,8 @@ def make_signal(rng, nrng, M, S, n):
     else:
         pulse = 1.0 - np.abs(j - rng.uniform(0, S - 1)) / S
     amp = 10.0 ** rng.uniform(-3.5, 2.5)
+    if EXTREME and rng.random() < EXTREME:  # (PSK_FUZZ_EXTREME=p: energies that overflow or vanish in float)
+        amp = 10.0 ** rng.choice([rng.uniform(17.0, 19.5), rng.uniform(-24.0, -18.0), rng.uniform(9.0, 17.0)])
     cfo = rng.choice([0.0, 1e-3, 1e-2, 0.2]) * rng.uniform(-1, 1) / M
     ph = 2 * np.pi * k / M + rng.uniform(0, 2 * np.pi)
     x = np.repeat(np.exp(1j * ph), S) * np.tile(pulse, n_sym)
