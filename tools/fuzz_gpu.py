@@ -18,6 +18,10 @@ from psk_soft_amd import lib as pl  # noqa: E402
 
 NONFINITE = float(os.environ.get("PSK_FUZZ_NONFINITE", "0"))
 EXTREME = float(os.environ.get("PSK_FUZZ_EXTREME", "0"))
+# PSK_FUZZ_M: constellation sizes to draw from (default 2, 4, 4, 8; others -- 1, 3, 16 -- produce no bits, cpp/psk_soft.cpp:384-390);
+# PSK_FUZZ_XD: SRI.xdelta values to draw from, one per channel (default 0.01 for all: LinearFit::xdelta = (float)(1 / sampleRate))
+M_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_M"].split(",")] if os.environ.get("PSK_FUZZ_M") else [2, 4, 4, 8]
+XD_CHOICES = [float(v) for v in os.environ["PSK_FUZZ_XD"].split(",")] if os.environ.get("PSK_FUZZ_XD") else [0.01]
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
@@ -100,7 +104,7 @@ def main():
         for c in range(C):
             S = rng.choice(S_CHOICES)
             A = rng.choice(A_CHOICES)
-            M = rng.choice([2, 4, 4, 8])
+            M = rng.choice(M_CHOICES)
             n = rng.choice(N_CHOICES)
             p = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=n, differentialDecoding=int(rng.random() < 0.25))
             N = max(S * rng.choice([50, 300, 1200, 3000, 12000]), 64)
@@ -137,6 +141,7 @@ def main():
         ref = [dict(soft=[], bits=[], phase=[], index=[]) for _ in range(C)]
         pos = [0] * C
         first = [True] * C
+        xds = [XD_CHOICES[(rnd * 7 + c) % len(XD_CHOICES)] for c in range(C)]
         # walk the scripts in lock step: one batched call per "tick"
         while any(pos[c] < len(scripts[c]) for c in range(C)):
             pk = []
@@ -152,8 +157,8 @@ def main():
                     ev = scripts[c][pos[c]]
                 a, b, flushed = ev[1], ev[2], ev[3]
                 data = sigs[c][2 * a : 2 * b]
-                pk.append(dict(data=data, xdelta=XD, sriChanged=first[c], inputQueueFlushed=flushed))
-                r = oracles[c].service(data, XD, sriChanged=first[c], inputQueueFlushed=flushed)
+                pk.append(dict(data=data, xdelta=xds[c], sriChanged=first[c], inputQueueFlushed=flushed))
+                r = oracles[c].service(data, xds[c], sriChanged=first[c], inputQueueFlushed=flushed)
                 for k, v in (("soft", r.soft), ("bits", r.bits), ("phase", r.phase), ("index", r.index)):
                     ref[c][k].append(v)
                 first[c] = False
