@@ -309,6 +309,7 @@ struct psk_soft_handle {
                            // a call reported a first guess that failed (pf.hint, a word the kernels write into page-locked memory)
     int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
     int opt_ties_in_place = 1;              // PSK_SOFT_TIES_IN_PLACE=0 (environment): PLAN_TIES_HANDOVER in every plan (tests, A/B runs)
+    int opt_trace = 0;                      // PSK_SOFT_TRACE_LAUNCHES=1 (environment, debugging): see `mark` in process_round
     int opt_split = 2;                      // PSK_SOFT_SPLIT_CLASSES=n (environment): pieces a mixed batch's calls are cut into (0 / 1: never)
     int opt_pipe = 1;                       // PSK_SOFT_PIPELINED=0 (environment): never the pipelined mode (A/B runs)
     hipStream_t pipe_st[2] = {};            // its fit and back streams (the front stage stays on the class's stream)
@@ -437,6 +438,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
         h->opt_tiled = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_TIES_IN_PLACE"))
         h->opt_ties_in_place = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PSK_SOFT_TRACE_LAUNCHES"))
+        h->opt_trace = std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_SPLIT_CLASSES"))
         h->opt_split = std::atoi(e) < 0 ? 0 : std::atoi(e) > 16 ? 16 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_PIPELINED"))
@@ -1167,7 +1170,31 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         while (y < n_max + 128u) y <<= 1;
         return y;
     };
+    // PSK_SOFT_TRACE_LAUNCHES=1 (debugging a faulting kernel): in front of every launch the host waits for everything enqueued so
+    // far and writes one line for the launch and one per channel of its list to stderr -- the last launch named in the log of a
+    // run that died is the one that did it, with the shapes it was given.  (=2: the launch lines only.)
+    auto mark = [&](const char *what, int S, int H, uint32_t off, uint32_t cnt, uint32_t tiles, uint32_t y_len, uint32_t r_len) -> hipError_t {
+        if (!h->opt_trace)
+            return hipSuccess;
+        if (const hipError_t e = hipDeviceSynchronize())
+            return e;
+        std::fprintf(stderr, "[psk_soft] ok; next: %s S=%d H=%d ch0=%u cnt=%u tiles=%u y_len=%u r_len=%u slot=%d stream=%p\n", what, S, H, ch0, cnt,
+                     tiles, y_len, r_len, slot, (void *)stream);
+        for (uint32_t i = 0; i < cnt && h->opt_trace == 1; i++) {
+            const uint32_t bi = stamped || off == ~0u ? i : h_list[off + i];
+            const psk::ChanPlan &p = plans[bi];
+            if (off == ~0u && p.mode == psk::PLAN_SKIP)
+                continue;
+            std::fprintf(stderr, "[psk_soft]   ch %u mode=%u S=%u A=%u M=%u n=%u len0=%u n_out=%llu n_in=%llu L0=%u L1=%u flags=0x%x K=%u tbase=%u toff=%llu in=%p\n",
+                         ch0 + bi, p.mode, p.S, p.A, p.M, p.lf_n, p.lf_len0, (unsigned long long)p.n_out, (unsigned long long)p.n_in, p.ring_len0,
+                         p.ring_len1, p.lf_flags, p.tile_blocks, p.tile_base, (unsigned long long)p.tile_off, (const void *)p.in);
+        }
+        std::fflush(stderr);
+        return hipSuccess;
+    };
     auto enqueue = [&]() -> psk_soft_status {
+        if (any_quiet)
+            PSK_HIP(mark("fast<0,1> (calls that emit nothing)", 0, 1, off_quiet, res.cnt_quiet, 0, ring_floats(res.max_n_quiet, 512u), 0));
         if (any_quiet)
             PSK_HIP(psk::launch_fast(0, 1, 0, h->d_plans[slot], d_list + off_quiet, ch0, res.cnt_quiet, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                      h->lim.fit_cap, ring_floats(res.max_n_quiet, 512u), 0u, stream));
@@ -1180,14 +1207,19 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         // deepest histories (fewest waves per CU, longest tails) are launched first.
         if (res.cnt_any) {
             const uint32_t y_len = ring_floats(res.max_n_any, 512u);
+            PSK_HIP(mark("tile_front_any", (int)res.max_S_any, 0, off_any, res.cnt_any, tiles_max_any, y_len, 0));
             PSK_HIP(psk::launch_tile_front_any(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, res.max_S_any, h->d_state, h->d_ring,
                                                h->lim.ring_cap, h->d_tiles, h->d_traw, h->d_ts, h->pf.chan, stream));
+            if (h->opt_pfit)
+                PSK_HIP(mark("pfit (any)", (int)res.max_S_any, 0, off_any, res.cnt_any, tiles_max_any, y_len, pf_second));
             if (h->opt_pfit)
                 PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_ring,
                                          h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, h->pf,
                                          pf_second, stream));
+            PSK_HIP(mark("tile_fit (any)", (int)res.max_S_any, 0, off_any, res.cnt_any, tiles_max_any, y_len, 0));
             PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, h->d_state, h->d_ring, h->lim.ring_cap,
                                          h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test, h->pf, stream));
+            PSK_HIP(mark("tile_back (any)", (int)res.max_S_any, 0, off_any, res.cnt_any, tiles_max_any, y_len, 0));
             PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_any, ch0, res.cnt_any, tiles_max_any, h->d_state, h->d_tiles,
                                           h->d_ts, h->d_test, 0u, 0u, stream));
         }
@@ -1262,24 +1294,31 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 PSK_HIP(hipStreamWaitEvent(st, h->pipe_ev[e], 0));
             } else if (tiled_SH[S][H]) {
                 // (a call these cannot carry comes out with guard 1 and nothing committed: the launches below redo it)
+                PSK_HIP(mark("tile_front", S, H, off_SH[S][H], res.cnt_SH[S][H], tiles_max_SH[S][H], y_len, r_len));
                 PSK_HIP(psk::launch_tile_front(S, class_H(H), h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H],
                                                h->d_state, h->d_ring, h->lim.ring_cap, r_len, h->d_tiles, h->d_traw, h->d_ts,
                                                h->pf.chan, 0u, st));
                 if (h->opt_pfit)
+                    PSK_HIP(mark("pfit", S, H, off_SH[S][H], res.cnt_SH[S][H], tiles_max_SH[S][H], y_len, pf_second));
+                if (h->opt_pfit)
                     PSK_HIP(psk::launch_pfit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                              h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts,
                                              h->d_test, h->pf, pf_second, st));
+                PSK_HIP(mark("tile_fit", S, H, off_SH[S][H], res.cnt_SH[S][H], tiles_max_SH[S][H], y_len, r_len));
                 PSK_HIP(psk::launch_tile_fit(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring,
                                              h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, h->d_tiles, h->d_traw, h->d_ts, h->d_test,
                                              h->pf, st));
+                PSK_HIP(mark("tile_back", S, H, off_SH[S][H], res.cnt_SH[S][H], tiles_max_SH[S][H], y_len, r_len));
                 PSK_HIP(psk::launch_tile_back(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], tiles_max_SH[S][H], h->d_state,
                                               h->d_tiles, h->d_ts, h->d_test, 0u, 0u, st));
             }
             // (the exact tier only works on the calls the tier in front of it left; behind the time-tiled kernels, whose front
             // stage IS the screened timing, it is the exact tier that picks up what they hand over)
-            for (int exact = tiled_SH[S][H] ? 1 : 0; exact <= 1; exact++)
+            for (int exact = tiled_SH[S][H] ? 1 : 0; exact <= 1; exact++) {
+                PSK_HIP(mark(exact ? "fast (exact tier)" : "fast (screened tier)", S, H, off_SH[S][H], res.cnt_SH[S][H], 0, y_len, r_len));
                 PSK_HIP(psk::launch_fast(S, class_H(H), exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
+            }
             if (deferred)  // (the class's hand-overs are redone on its own stream, in front of its next call)
                 PSK_HIP(psk::launch_seq(h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state, h->d_ring, h->lim.ring_cap,
                                         h->d_yv, h->lim.fit_cap, st));
@@ -1299,6 +1338,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 PSK_HIP(hipEventRecord(h->aux_join[a], h->aux[a]));
                 PSK_HIP(hipStreamWaitEvent(stream, h->aux_join[a], 0));
             }
+            if (any_seq || any_emit)
+                PSK_HIP(mark("seq (reference order)", 0, 0, ~0u, nch, 0, 0, 0));
             if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
                 PSK_HIP(psk::launch_seq(h->d_plans[slot], nullptr, ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                         h->lim.fit_cap, stream));

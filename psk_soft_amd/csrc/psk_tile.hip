@@ -321,7 +321,9 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                 for (int u = 0; u < U; u++) {
                     const int i = i0 + u;
                     const bool live = i < i_end;
-                    const int kbest = (int)k_win[u];
+                    // (every sum NaN -- a window of overflowing energies: inf arrives, inf - inf leaves -- and no lane holds the maximum.
+                    // The tile refuses, energy_at has seen to that; the pick still has to be a sample of the symbol, it is fetched below)
+                    const int kbest = k_win[u] < (unsigned)S ? (int)k_win[u] : 0;
                     k_last = live ? kbest : k_last;
                     wmax = live ? __builtin_fmaxf(wmax, (float)best[u] * 1.0000002f) : wmax;
                     const float g = (float)(best[u] - second[u]) / (2.0f * drift_bound(i + 1 + kB, (uint32_t)A));
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(64) void psk_tile_front_any_kernel(const ChanPlan *
                     }
                 }
                 // (`top`: this lane's own phases.  The wave's largest sum; the lowest phase that holds it; the largest of all the others --
-                // the winner's lane puts up the runner-up among its own.  The sums are finite, or the tile refuses.)
+                // the winner's lane puts up the runner-up among its own.  The sums are finite, or the tile refuses -- but runs to its end.)
                 const double best = any_max_f64(top.best);
                 const unsigned k_win = any_min_u32(top.best == best ? (unsigned)top.k : 0xFFFFFFFFu);
                 const double second = any_max_f64((unsigned)top.k == k_win ? top.second : top.best);
-                const int kbest = (int)k_win;
+                const int kbest = k_win < (unsigned)S ? (int)k_win : 0;  // (every sum NaN: see above -- k_win is AnyTop's sentinel then)
                 k_last = live ? kbest : k_last;
                 const float best_f = (float)best;
                 wmax = live ? __builtin_fmaxf(wmax, best_f * 1.0000002f) : wmax;

@@ -389,6 +389,32 @@ def test_run_time_front_hands_over(oracle_mod):
         h.close()
 
 
+@pytest.mark.parametrize("S,A", [(100, 20), (64, 30), (33, 100), (300, 5)])
+def test_run_time_front_with_every_window_sum_nan(oracle_mod, S, A):
+    """Samples of magnitude 3e19: every energy overflows float, the window sums go to inf as the symbols arrive and to
+    inf - inf = NaN as they leave -- in EVERY phase, so no phase holds the maximum.  The run-time front stage refuses such a
+    tile (non-finite energies), but it runs to its end and fetches the sample of its "pick": with more than one phase a lane
+    that was the sentinel index of an empty comparison, 16 GiB behind the packet -- a GPU memory fault (found by the randomised
+    comparison, seed 20270130 round 9 with samplesPerBaud up to 100 and PSK_FUZZ_EXTREME).  The pick is now a sample of the
+    symbol whatever the sums are; the call is the reference-order kernel's and carries the oracle's values."""
+    M = 4
+    iq = np.empty(2 * S * 1500, np.float32)
+    rng = np.random.default_rng(S)
+    ph = 2 * np.pi * rng.integers(0, M, 1500) / M + 0.3
+    x = np.repeat(np.exp(1j * ph), S) * 3.0e19  # (a rectangular pulse: no phase stays finite)
+    iq[0::2] = x.real.astype(np.float32)
+    iq[1::2] = x.imag.astype(np.float32)
+    props = dict(samplesPerBaud=S, constelationSize=M, numAvg=A, phaseAvg=50)
+    ref = oracle_run(oracle_mod, iq, props, packet=S * 700 + 13)
+    h = _handle(1, max_window_samples=S * A + 64)
+    h.configure(0, [props])
+    got = run_gpu(h, 0, iq, 0.01, S * 700 + 13)
+    st = h.stats()
+    assert st["channels_sequential"] == 1 and st["channels_guard"] == 1, st
+    assert_parity(got, ref, "S%d A%d" % (S, A))
+    h.close()
+
+
 def test_more_channels_than_a_grid_dimension(oracle_mod):
     """A window class that always goes through the time-tiled kernels (samplesPerBaud 40: no wave-scan instantiation) with more
     channels than the y dimension of a grid holds (65535): the launches go out in slices of the class's channel list."""

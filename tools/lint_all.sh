@@ -15,6 +15,14 @@ one() { IFS=, read s h e <<< "$1"; extra="";
   python3 tools/isa_lane_loss.py $2/k_${s}_${h}_${e}.s --sites 3 | sed "s/^k_/LANES S,H,E = /" >> $2/lanes.txt; rm -f $2/k_${s}_${h}_${e}.s; }
 export -f one
 echo $list | tr ' ' '\n' | grep . | xargs -P 8 -I{} bash -c "one {} $tmp" > $out.unsorted
-sort -t_ -k2,2n -k3,3n -k4,4n $out.unsorted > $out; rm -f $out.unsorted; cp $tmp/lanes.txt $out.lanes; rm -f $tmp/lanes.txt; rmdir $tmp
+sort -t_ -k2,2n -k3,3n -k4,4n $out.unsorted > $out; rm -f $out.unsorted; cp $tmp/lanes.txt $out.lanes; rm -f $tmp/lanes.txt
+# the other translation units: the time-tiled kernels and the parallel fit (psk_tile.hip), the reference-order kernel (psk_kernels.hip),
+# the instantiated front stages (psk_tile_inst.hip, samplesPerBaud 2 ... 16)
+FL="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-unused-function -Iinclude -Ipsk_soft_amd/csrc --cuda-device-only -S"
+others() { f=$1; shift; /opt/rocm/bin/hipcc $FL "$@" -o $tmp/$f.s psk_soft_amd/csrc/${f%%@*}.hip 2>/dev/null
+  python3 tools/isa_exec_spills.py $tmp/$f.s --sites 0 >> $out; python3 tools/isa_lane_loss.py $tmp/$f.s --sites 3 >> $out.lanes; rm -f $tmp/$f.s; }
+others psk_tile; others psk_kernels
+for s in $(seq 2 16); do others psk_tile_inst@S$s -DPSK_INST_S=$s -DPSK_INST_H=1; done
 echo "instantiations with D sites / with E sites (tools/isa_lane_loss.py):"; grep -c "no covering save) [1-9]" $out.lanes; grep -c "mask restore) [1-9]" $out.lanes
 grep -c . $out; grep -v "C (lane carrier moved under a partial mask) 0" $out | wc -l
+rmdir $tmp
