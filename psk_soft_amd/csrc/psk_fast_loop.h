@@ -585,11 +585,14 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
         tf = tf * xd;
         tt[r] = (double)tf;
     }
+    // (the value a step takes from the lane below lands in the register that held it the step before: a DPP move leaves lane 0,
+    // which has no lane below, as it was -- the carried sum, put there once.  Handing the constant in at every step instead cost
+    // two register moves a step, a quarter of the chain's instructions.)
     if (with_y) {
-        double ys = ySum_c;
+        double ys = ySum_c, a = ySum_c;
 #pragma unroll 1
         for (int k = 0; k <= lane_last; k++) {
-            const double a = wave_up1(ys, ySum_c);
+            a = wave_up1(ys, a);
             ySum_l[0] = (a - zz[0]) + yy[0];  // ySum -= yvals.front(), :70;  ySum += yval, :77
             ySum_l[1] = (ySum_l[0] - zz[1]) + yy[1];
             ys = ySum_l[1];
@@ -599,17 +602,17 @@ PSK_DEV void fit_sums_chain(bool with_y, int lane, int lane_last, uint32_t q0, u
     const double ys_prev = wave_up1(ySum_l[1], ySum_c);
     const double c0 = steady[0] ? xdd * (ys_prev - zz[0]) : 0.0;
     const double c1 = steady[1] ? xdd * (ySum_l[0] - zz[1]) : 0.0;
-    double xs = xySum_c;
+    double xs = xySum_c, b = xySum_c;
     const int steps = PSK_CHAIN_UNROLL * ((lane_last + PSK_CHAIN_UNROLL) / PSK_CHAIN_UNROLL);  // (extra steps recompute final values)
 #pragma unroll 1
     for (int k = 0; k < steps; k += PSK_CHAIN_UNROLL) {
 #pragma unroll
         for (int u = 0; u < PSK_CHAIN_UNROLL; u++) {
-            const double b = wave_up1(xs, xySum_c);
+            b = wave_up1(xs, b);
             xs = ((b - c0) + tt[0] - c1) + tt[1];  // :72 and :78, twice
         }
     }
-    const double b_fin = wave_up1(xs, xySum_c);
+    const double b_fin = wave_up1(xs, b);
     xySum_l[0] = (b_fin - c0) + tt[0];
     xySum_l[1] = xs;
 }

@@ -71,6 +71,14 @@ e1.record(stream)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / reps * 1e6
 print("issue     : %7.1f us per call (CPU, no sync)" % issue)
+# (a call waits for the plan slot it is about to reuse -- four slots --, so a long run of calls is throttled to the device's pace:
+# the CPU's own cost of a call shows in bursts shorter than that, each behind a synchronize)
+burst = []
+for _ in range(300):
+    torch.cuda.synchronize()
+    burst.append(run(h, 3, stream.cuda_stream))
+burst.sort()
+print("issue     : %7.1f us per call (CPU, bursts of three calls behind a synchronize: median; min %.1f)" % (burst[len(burst) // 2], burst[0]))
 print("steady    : %7.1f us per call (wall, %d calls back to back)" % (wall, reps))
 print("device    : %7.1f us per call (HIP events)" % (e0.elapsed_time(e1) / reps * 1e3))
 # the same batch fed in G slices on G streams: the tail of one slice's launch (its slowest waves) overlaps the body of the next's
