@@ -22,6 +22,9 @@ EXTREME = float(os.environ.get("PSK_FUZZ_EXTREME", "0"))
 # PSK_FUZZ_XD: SRI.xdelta values to draw from, one per channel (default 0.01 for all: LinearFit::xdelta = (float)(1 / sampleRate))
 M_CHOICES = [int(v) for v in os.environ["PSK_FUZZ_M"].split(",")] if os.environ.get("PSK_FUZZ_M") else [2, 4, 4, 8]
 XD_CHOICES = [float(v) for v in os.environ["PSK_FUZZ_XD"].split(",")] if os.environ.get("PSK_FUZZ_XD") else [0.01]
+# PSK_FUZZ_MORE=1: two more kinds of events in the scripts -- samplesPerBaud changed between two calls, and a new SRI (another
+# xdelta, sriChanged set) in the middle of a stream (off by default: the draws of the seeds quoted in DESIGN.md stay what they were)
+MORE = os.environ.get("PSK_FUZZ_MORE", "0") != "0"
 TOL = 1e-5
 STRICT = os.environ.get("PSK_FUZZ_STRICT", "1") != "0"  # every float of soft / phase must equal the oracle's
 XD = 0.01
@@ -120,7 +123,13 @@ def main():
                            "constelationSize": rng.choice([2, 4, 8]), "resetState": 1,
                            "differentialDecoding": rng.choice([0, 1])}[key]
                     ev.append(("set", key, val))
-                ev.append(("packet", prev, cut, rng.random() < 0.05))
+                new_xd = None
+                if MORE:
+                    if rng.random() < 0.08:
+                        ev.append(("set", "samplesPerBaud", rng.choice([v for v in S_CHOICES if v * 300 <= 33 * 1024] or S_CHOICES)))
+                    if rng.random() < 0.1:
+                        new_xd = rng.choice([0.01, 0.02, 1e-3, 0.5, 2.5e-7])
+                ev.append(("packet", prev, cut, rng.random() < 0.05, new_xd))
                 prev = cut
             props.append(p)
             sigs.append(sig)
@@ -157,8 +166,12 @@ def main():
                     ev = scripts[c][pos[c]]
                 a, b, flushed = ev[1], ev[2], ev[3]
                 data = sigs[c][2 * a : 2 * b]
-                pk.append(dict(data=data, xdelta=xds[c], sriChanged=first[c], inputQueueFlushed=flushed))
-                r = oracles[c].service(data, xds[c], sriChanged=first[c], inputQueueFlushed=flushed)
+                sri = first[c]
+                if len(ev) > 4 and ev[4] is not None:  # (PSK_FUZZ_MORE: a new SRI in front of this packet)
+                    xds[c] = ev[4]
+                    sri = True
+                pk.append(dict(data=data, xdelta=xds[c], sriChanged=sri, inputQueueFlushed=flushed))
+                r = oracles[c].service(data, xds[c], sriChanged=sri, inputQueueFlushed=flushed)
                 for k, v in (("soft", r.soft), ("bits", r.bits), ("phase", r.phase), ("index", r.index)):
                     ref[c][k].append(v)
                 first[c] = False
