@@ -1192,6 +1192,9 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
         std::fflush(stderr);
         return hipSuccess;
     };
+    // (timing experiments only -- PSK_SOFT_DIAG_NO_TAIL=1: the exact-timing and reference-order launches behind the screened tier are
+    // left out, which is wrong as soon as a call is handed over; what the two launches cost a small call is measured that way)
+    static const bool diag_no_tail = std::getenv("PSK_SOFT_DIAG_NO_TAIL") && std::atoi(std::getenv("PSK_SOFT_DIAG_NO_TAIL")) != 0;
     auto enqueue = [&]() -> psk_soft_status {
         if (any_quiet)
             PSK_HIP(mark("fast<0,1> (calls that emit nothing)", 0, 1, off_quiet, res.cnt_quiet, 0, ring_floats(res.max_n_quiet, 512u), 0));
@@ -1315,6 +1318,8 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             // (the exact tier only works on the calls the tier in front of it left; behind the time-tiled kernels, whose front
             // stage IS the screened timing, it is the exact tier that picks up what they hand over)
             for (int exact = tiled_SH[S][H] ? 1 : 0; exact <= 1; exact++) {
+                if (exact && diag_no_tail)
+                    break;
                 PSK_HIP(mark(exact ? "fast (exact tier)" : "fast (screened tier)", S, H, off_SH[S][H], res.cnt_SH[S][H], 0, y_len, r_len));
                 PSK_HIP(psk::launch_fast(S, class_H(H), exact, h->d_plans[slot], d_list + off_SH[S][H], ch0, res.cnt_SH[S][H], h->d_state,
                                          h->d_ring, h->lim.ring_cap, h->d_yv, h->lim.fit_cap, y_len, r_len, st));
@@ -1340,7 +1345,7 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
             }
             if (any_seq || any_emit)
                 PSK_HIP(mark("seq (reference order)", 0, 0, ~0u, nch, 0, 0, 0));
-            if (any_seq || any_emit)  // any_emit: the exactness guard may hand calls over at run time
+            if ((any_seq || any_emit) && !diag_no_tail)  // any_emit: the exactness guard may hand calls over at run time
                 PSK_HIP(psk::launch_seq(h->d_plans[slot], nullptr, ch0, nch, h->d_state, h->d_ring, h->lim.ring_cap, h->d_yv,
                                         h->lim.fit_cap, stream));
         }
