@@ -310,6 +310,7 @@ struct psk_soft_handle {
     int pf_second_ttl = 0;  // tiled calls left with the second round enqueued
     int opt_ties_in_place = 1;              // PSK_SOFT_TIES_IN_PLACE=0 (environment): PLAN_TIES_HANDOVER in every plan (tests, A/B runs)
     int opt_trace = 0;                      // PSK_SOFT_TRACE_LAUNCHES=1 (environment, debugging): see `mark` in process_round
+    int opt_validate = 0;                   // PSK_SOFT_VALIDATE=1 (environment, tests): see `validate` in process_round
     int opt_split = 2;                      // PSK_SOFT_SPLIT_CLASSES=n (environment): pieces a mixed batch's calls are cut into (0 / 1: never)
     int opt_pipe = 1;                       // PSK_SOFT_PIPELINED=0 (environment): never the pipelined mode (A/B runs)
     hipStream_t pipe_st[2] = {};            // its fit and back streams (the front stage stays on the class's stream)
@@ -440,6 +441,8 @@ psk_soft_status psk_soft_create(int device, uint32_t n_channels, const psk_soft_
         h->opt_ties_in_place = std::atoi(e) != 0;
     if (const char *e = std::getenv("PSK_SOFT_TRACE_LAUNCHES"))
         h->opt_trace = std::atoi(e);
+    if (const char *e = std::getenv("PSK_SOFT_VALIDATE"))
+        h->opt_validate = std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_SPLIT_CLASSES"))
         h->opt_split = std::atoi(e) < 0 ? 0 : std::atoi(e) > 16 ? 16 : std::atoi(e);
     if (const char *e = std::getenv("PSK_SOFT_PIPELINED"))
@@ -1094,6 +1097,49 @@ static psk_soft_status process_round(psk_soft_handle_t *h, uint32_t ch0, uint32_
                 for (hipStream_t &q : h->pipe_st) PSK_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, prio_hi));
                 for (hipEvent_t &e : h->pipe_ev) PSK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
+        }
+    }
+    // PSK_SOFT_VALIDATE=1 (tests, the randomised comparison): what the kernels take for granted about a plan -- the samples a call
+    // reads exist, what it leaves behind fits the rings, its place in the scratch of the time-tiled kernels lies inside it -- is
+    // checked here, on the host, in front of the first launch; a violation refuses the call (nothing enqueued, nothing committed)
+    // instead of sending a kernel out of bounds.
+    if (h->opt_validate) {
+        const char *why = nullptr;
+        uint32_t bad = 0;
+        for (uint32_t i = 0; i < nch && !why; i++) {
+            const psk::ChanPlan &p = plans[i];
+            if (p.mode == psk::PLAN_SKIP)
+                continue;
+            bad = i;
+            const uint64_t S = p.S ? p.S : 1u, have = (uint64_t)p.ring_len0 + p.n_in;
+            const uint64_t nb = (p.n_out + 127u) / 128u;
+            if (p.n_out && p.S > 1u && (p.n_out + p.A - 1u) * S > have)
+                why = "the call reads samples behind the packet's end";
+            else if (p.n_out && p.S <= 1u && p.mode != psk::PLAN_SEQ_S1 && p.n_out > p.n_in)
+                why = "more symbols than samples at one sample per symbol";
+            else if (p.ring_len0 > h->lim.ring_cap || p.ring_len1 > h->lim.ring_cap || p.ring_src > 1u)
+                why = "carried samples beyond the ring";
+            else if (p.ring_len1 > have)
+                why = "more samples carried out of the call than it holds";
+            else if (p.lf_n >= h->lim.fit_cap || p.lf_len0 > p.lf_n || p.lf_head >= h->lim.fit_cap)
+                why = "LinearFit window beyond its ring";
+            else if ((p.lf_flags & psk::PLAN_TILED) && p.mode == psk::PLAN_FAST && p.n_out &&
+                     (!p.tile_blocks || p.tile_off + nb * 128u > h->tile_sym_cap ||
+                      (uint64_t)p.tile_base + (nb + p.tile_blocks - 1u) / p.tile_blocks > h->tile_cap))
+                why = "place in the time-tiled scratch outside it";
+            else if ((p.lf_flags & psk::PLAN_PFIT) && p.mode == psk::PLAN_FAST && p.n_out &&
+                     (p.tile_off + nb * 128u > h->pf_sym_cap || (uint64_t)p.tile_base + (nb + p.tile_blocks - 1u) / p.tile_blocks > h->pf_cap))
+                why = "place in the parallel fit's scratch outside it";
+            else if (p.mode == psk::PLAN_FAST && p.n_out && !(p.lf_flags & psk::PLAN_ANYFRONT) &&
+                     (p.S < 2u || p.S > 32u || p.A > 1024u || (p.S > 16u && p.A > 512u)))
+                why = "window class without a wave-scan instantiation planned for one";
+            else if (p.mode == psk::PLAN_FAST && p.n_out > psk::kResyncCount)
+                why = "a piece longer than 2^20 symbols on the wave-scan kernels";
+        }
+        if (why) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "psk_soft_process: plan of channel %u fails validation: %s", ch0 + bad, why);
+            return fail(PSK_SOFT_ERR_LIMIT, buf);
         }
     }
     // window classes of the call in launch order (deepest history first); class 0 stays on the caller's stream, the others take

@@ -415,6 +415,18 @@ def test_run_time_front_with_every_window_sum_nan(oracle_mod, S, A):
     h.close()
 
 
+def test_plans_pass_the_host_side_validation(oracle_mod, monkeypatch):
+    """PSK_SOFT_VALIDATE=1: in front of the first launch of a call the host checks what the kernels take for granted about every
+    plan (the samples a call reads exist, what it carries out fits the rings, its place in the scratch of the time-tiled kernels
+    and of the parallel fit lies inside them) and refuses the call otherwise.  The batches below -- window classes side by side,
+    tiled and not, ragged calls, the run-time front stage and its hand-over -- pass it, with the oracle's values.  (The randomised
+    comparison runs under the switch too: DESIGN.md section 4.)"""
+    monkeypatch.setenv("PSK_SOFT_VALIDATE", "1")
+    test_tiled_mixed_batch_with_carried_state(oracle_mod)
+    test_run_time_front_hands_over(oracle_mod)
+    test_window_classes_without_an_instantiation(oracle_mod, 4, 100, 0, 30, 10, 100 * 1500, 100 * 500 + 3)
+
+
 def test_more_channels_than_a_grid_dimension(oracle_mod):
     """A window class that always goes through the time-tiled kernels (samplesPerBaud 40: no wave-scan instantiation) with more
     channels than the y dimension of a grid holds (65535): the launches go out in slices of the class's channel list."""
