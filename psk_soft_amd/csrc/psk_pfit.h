@@ -462,19 +462,41 @@ PSK_DEV bool pf_x_ok(double s_c, const bool (&valid)[kR], const double (&c)[kR],
 // ---- pf_xwalk: one wave per channel ----
 // the block's recurrence itself, as the block-by-block kernels run it: candidates from the true carried sum and their
 // certificate (try_grid), else the recurrence lane after lane; the 128 sums go to xs_row, the last valid one is returned
-PSK_DEV double pf_walk_block(int lane, int b, int n_out, double s_c, const double *c_row, const float *t_row, double *xs_row, bool try_grid)
+struct PfOps {  // the two xySum operands of a lane's two positions (cpp/psk_soft.cpp:72, :78), as pf_ysum left them
+    double2 cv;
+    float2 tv;
+};
+PSK_DEV PfOps pf_load_ops(int lane, int b, const double *c_row, const float *t_row)
+{
+    const int i0 = b * kB + 2 * lane;  // (the per-symbol arrays are padded to whole blocks)
+    PfOps o;
+    o.cv = *reinterpret_cast<const double2 *>(c_row + i0);
+    o.tv = *reinterpret_cast<const float2 *>(t_row + i0);
+    return o;
+}
+PSK_DEV double pf_walk_block(int lane, int b, int n_out, double s_c, const PfOps &ops, double *xs_row, bool try_grid, bool &grid_failed)
 {
     const int i0 = b * kB + 2 * lane;
     const bool valid[kR] = {i0 < n_out, i0 + 1 < n_out};
-    const double2 cv = *reinterpret_cast<const double2 *>(c_row + i0);
-    const float2 tv = *reinterpret_cast<const float2 *>(t_row + i0);
+#ifdef PSK_DIAG_WALK_NOLOAD  // (timing experiments only: wrong sums, which the certificate of pf_verify turns into a refusal)
+    const double2 cv = make_double2(s_c * 0.25, s_c * 0.125);
+    const float2 tv = make_float2((float)lane, 1.0f);
+#else
+    const double2 cv = ops.cv;
+    const float2 tv = ops.tv;
+#endif
     const double cc[kR] = {valid[0] ? cv.x : 0.0, valid[1] ? cv.y : 0.0};
     const double tt[kR] = {valid[0] ? (double)tv.x : 0.0, valid[1] ? (double)tv.y : 0.0};
     double xs[kR];
     bool done = false;
-    if (try_grid) {  // (a block whose prepared range merely missed the sum is crossing a binade: the candidates cannot hold)
+#ifdef PSK_DIAG_WALK_NOCHAIN
+    xs[0] = s_c - cc[0], xs[1] = s_c - tt[1];
+    done = true;
+#endif
+    if (try_grid && !done) {  // (a block whose prepared range merely missed the sum is crossing a binade: the candidates cannot hold)
         xysum_grid(lane, s_c, cc, tt, xs);
         done = pf_x_ok(s_c, valid, cc, tt, xs);
+        grid_failed = !done;
     }
     if (!done) {
         double x = s_c;
@@ -526,6 +548,9 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
     double *xs_row = sc.xs + p.tile_off;
     double s_c = sc.chan[bi].xySum_c;
     uint32_t slow_blocks = 0;
+#ifdef PSK_DIAG_WALK_TIME
+    const unsigned long long t_begin = wall_clock64();  // (100 MHz)
+#endif
     int par = -1;  // parity of the carried sum in the scale of the block in front (wave-uniform; -1: not known)
     for (int b0 = 0; b0 < n_blocks; b0 += kWave) {
         const bool have = b0 + lane < n_blocks;
@@ -536,6 +561,9 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
         int slow_mine = 0;
         int start = 0;
         while (start < nb) {
+#ifdef PSK_DIAG_WALK_SCANS  // (diagnostic build: the statistic counts scan passes, a thousand each, next to the slow blocks)
+            slow_blocks += 1000u;
+#endif
             // parity the run starts with: carried, or from the sum where the scale is new
             const int fl_s = __builtin_amdgcn_readlane(rec.flags, start);
             if (par < 0 || !(fl_s & 4))
@@ -584,14 +612,35 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
                 start = f;
                 continue;
             }
-            if (lane == f) {
-                s_in_mine = s_c;
-                slow_mine = 1;
+            // Blocks the walker runs itself, one after the other for as long as the next one cannot be entered either (a
+            // channel whose sums hover around zero is such a run from end to end): no scan in between, and the next block's
+            // operands are asked for before this block's recurrence starts -- a run costs its recurrences and little else.
+            int fs = f;
+            PfOps ops = pf_load_ops(lane, b0 + fs, c_row, t_row);
+            bool grid_first = !(a_f < b_f);
+            bool grid_failed = false;  // (once the candidates of a block of the run have not verified, the rest of it goes straight to the recurrence)
+            for (;;) {
+                const bool more = fs + 1 < nb;
+                PfOps ahead = ops;
+                if (more)
+                    ahead = pf_load_ops(lane, b0 + fs + 1, c_row, t_row);
+                if (lane == fs) {
+                    s_in_mine = s_c;
+                    slow_mine = 1;
+                }
+                s_c = pf_walk_block(lane, b0 + fs, n_out, s_c, ops, xs_row, grid_first, grid_failed);
+                slow_blocks++;
+                start = fs + 1;
+                if (!more)
+                    break;
+                const double a_n = read_lane(rec.a, fs + 1), b_n = read_lane(rec.b, fs + 1);
+                if (a_n < s_c && s_c < b_n)
+                    break;  // (enterable: the scan resumes there)
+                fs++;
+                ops = ahead;
+                grid_first = !(a_n < b_n) && !grid_failed;
             }
-            s_c = pf_walk_block(lane, b0 + f, n_out, s_c, c_row, t_row, xs_row, !(a_f < b_f));
-            slow_blocks++;
             par = -1;
-            start = f + 1;
         }
         if (have) {
             PfWalk w;
@@ -601,6 +650,9 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
             walk[b0 + lane] = w;
         }
     }
+#ifdef PSK_DIAG_WALK_TIME  // (diagnostic build: the statistic is the walker's own duration, in units of 10 ns)
+    slow_blocks = (uint32_t)((wall_clock64() - t_begin) / 1u);
+#endif
     if (lane == 0)
         sc.chan[bi].slow_blocks = slow_blocks;
 }
