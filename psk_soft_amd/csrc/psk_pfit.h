@@ -180,10 +180,18 @@ __global__ __launch_bounds__(64) void pf_y_kernel(const ChanPlan *__restrict__ p
         if (!(__builtin_fabsf(states[ch0 + bi].lf_m) < kPfSteep))
             koff += (int)unwrap_count(states[ch0 + bi].phaseEstimate, (double)raw_row[0]);
     }  // (round 1: the counts are absolute already, corrected by pf_verify where the first guess was wrong)
+    // (a tile's blocks are independent here: the next block's operands are asked for before this one is worked on -- a wave
+    // otherwise pays a round trip to memory per block, and four such waves do not fill a SIMD's time)
+    float2 rw_n = *reinterpret_cast<const float2 *>(raw_row + g.c_begin * kB + 2 * g.lane);
+    int2 k_n = *reinterpret_cast<const int2 *>(k_row + g.c_begin * kB + 2 * g.lane);
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
-        const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
-        int2 k = *reinterpret_cast<const int2 *>(k_row + i0);
+        const float2 rw = rw_n;
+        int2 k = k_n;
+        if (c + 1 < g.c_end) {
+            rw_n = *reinterpret_cast<const float2 *>(raw_row + i0 + kB);
+            k_n = *reinterpret_cast<const int2 *>(k_row + i0 + kB);
+        }
         k.x += koff;
         k.y += koff;
         *reinterpret_cast<int2 *>(k_row + i0) = k;
@@ -207,12 +215,22 @@ __global__ __launch_bounds__(64) void pf_ydiff_kernel(const ChanPlan *__restrict
     const float *yv = yvs + (size_t)(ch0 + bi) * fit_cap;
     double *S_row = sc.S + g.off;
     double run = 0.0, dlast = 0.0;
+    // (the next block's operands asked for ahead, as in pf_y; positions past the end of the call read the padding of the row)
+    const int j0 = g.c_begin * kB + 2 * g.lane;
+    float2 y_n = *reinterpret_cast<const float2 *>(y_row + j0);
+    float z0_n = pf_z(p, y_row, yv, fit_cap, j0), z1_n = pf_z(p, y_row, yv, fit_cap, j0 + 1);
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
-        const float2 y = *reinterpret_cast<const float2 *>(y_row + i0);
+        const float2 y = y_n;
+        const float z0 = z0_n, z1 = z1_n;
+        if (c + 1 < g.c_end) {
+            y_n = *reinterpret_cast<const float2 *>(y_row + i0 + kB);
+            z0_n = pf_z(p, y_row, yv, fit_cap, i0 + kB);
+            z1_n = pf_z(p, y_row, yv, fit_cap, i0 + kB + 1);
+        }
         const bool v0 = i0 < g.n_out, v1 = i0 + 1 < g.n_out;
-        const double d0 = v0 ? (double)y.x - (double)pf_z(p, y_row, yv, fit_cap, i0) : 0.0;
-        const double d1 = v1 ? (double)y.y - (double)pf_z(p, y_row, yv, fit_cap, i0 + 1) : 0.0;
+        const double d0 = v0 ? (double)y.x - (double)z0 : 0.0;
+        const double d1 = v1 ? (double)y.y - (double)z1 : 0.0;
         const double incl = wave_scan_f64(d0 + d1);
         const double a0 = (run + wave_up1(incl, 0.0)) + d0;
         *reinterpret_cast<double2 *>(S_row + i0) = make_double2(a0, a0 + d1);
@@ -259,13 +277,25 @@ __global__ __launch_bounds__(64) void pf_ysum_kernel(const ChanPlan *__restrict_
     const float sizef = (float)(p.lf_n - 1u);  // (float)yvals.size() before the push, :78
     double S_before = soff;  // ySum after the symbol in front of the block
     double xrun = 0.0;
+    // (the next block's operands asked for ahead, as in pf_y)
+    const int j0 = g.c_begin * kB + 2 * g.lane;
+    float2 y_n = *reinterpret_cast<const float2 *>(y_row + j0);
+    double2 dl_n = *reinterpret_cast<const double2 *>(S_row + j0);
+    float z0_n = pf_z(p, y_row, yv, fit_cap, j0), z1_n = pf_z(p, y_row, yv, fit_cap, j0 + 1);
     for (int c = g.c_begin; c < g.c_end; c++) {
         const int i0 = c * kB + 2 * g.lane;
         const bool v0 = i0 < g.n_out, v1 = i0 + 1 < g.n_out;
-        const float2 y = *reinterpret_cast<const float2 *>(y_row + i0);
-        const double2 dl = *reinterpret_cast<const double2 *>(S_row + i0);
+        const float2 y = y_n;
+        const double2 dl = dl_n;
+        const float z0f = z0_n, z1f = z1_n;
+        if (c + 1 < g.c_end) {
+            y_n = *reinterpret_cast<const float2 *>(y_row + i0 + kB);
+            dl_n = *reinterpret_cast<const double2 *>(S_row + i0 + kB);
+            z0_n = pf_z(p, y_row, yv, fit_cap, i0 + kB);
+            z1_n = pf_z(p, y_row, yv, fit_cap, i0 + kB + 1);
+        }
         const double S0 = soff + dl.x, S1 = soff + dl.y;
-        const double z0 = v0 ? (double)pf_z(p, y_row, yv, fit_cap, i0) : 0.0, z1 = v1 ? (double)pf_z(p, y_row, yv, fit_cap, i0 + 1) : 0.0;
+        const double z0 = v0 ? (double)z0f : 0.0, z1 = v1 ? (double)z1f : 0.0;
         const double Sp = wave_up1(S1, S_before);
         const double a0 = Sp - z0, a1 = S0 - z1;  // ySum after the pop, :70
         bad = bad || (v0 && !same_bits(a0 + (double)y.x, S0)) || (v1 && !same_bits(a1 + (double)y.y, S1));  // :77
