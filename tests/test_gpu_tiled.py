@@ -304,6 +304,34 @@ def test_parallel_fit_large_carrier_offset(oracle_mod):
         h.close()
 
 
+def test_parallel_fit_walks_runs_of_blocks_itself(oracle_mod):
+    """Channels without a carrier offset whose constellation sits a few hundredths of a radian off zero phase (channel 14 of the
+    128-channel sweep point of tools/walker_hist.py: offset 0, M * phi0 = 0.077): LinearFit's sums hover where practically no
+    block can be entered with a prepared map, and the walker (pf_xwalk, psk_pfit.h) walks runs of blocks itself -- one after the
+    other without a scan in between, the next block's operands requested ahead, the grid candidates tried once per run.  Next to
+    it exactly zero phase (the signal shape of the reference's own test, reference tests/test_psk_soft.py:98-117), 8-PSK with
+    differential decoding, a call that ends in a partial block and one of more than 64 blocks (a run across the walker's rounds);
+    three calls each (the runs start from carried sums).  Bit for bit, and on the parallel fit: a refusal would hide the path
+    behind the block-by-block kernel."""
+    from psk_soft_amd.stimulus import synth_channel
+
+    walked = []
+    for M, S, n, diff, mphi0, npk in ((4, 8, 50, 0, 0.0766, 1 << 16), (4, 8, 50, 0, 0.0, (1 << 16) - 40), (8, 10, 200, 1, 0.05, 70 * 1280 + 30),
+                                      (2, 4, 17, 0, 0.03, 1 << 15), (4, 8, 50, 0, -0.02, 1 << 17)):
+        iq = synth_channel(131 + M, M, S, 3 * npk, cfo=0.0, phi0=mphi0 / M)
+        props = dict(samplesPerBaud=S, constelationSize=M, numAvg=100, phaseAvg=n, differentialDecoding=diff)
+        ref = oracle_run(oracle_mod, iq, props, packet=npk)
+        h = _tiled_handle()
+        h.configure(0, [props])
+        got = run_gpu(h, 0, iq, 0.01, npk)
+        st = h.stats()
+        assert st["channels_parallel_fit"] == 1 and st["parallel_fit_refusals"] == 0, st
+        walked.append((st["fit_chain_blocks"], (npk // S + 127) // 128))
+        assert_parity(got, ref, "hovering M%d M*phi0 %.3f" % (M, mphi0))
+        h.close()
+    assert any(w >= nb // 4 for w, nb in walked), walked  # (a quarter of some call's blocks walked by the wave itself: runs)
+
+
 def test_tiled_device_batch_auto(oracle_mod):
     """64 channels x 2^16 samples through the device-pointer entry point: the automatic choice tiles them; spot
     channels against the oracle."""
