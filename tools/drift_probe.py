@@ -44,6 +44,15 @@ def measure(steps=20):
 for _ in range(5):
     h.process_device(0, pk, out, stream=stream.cuda_stream)
 torch.cuda.synchronize(dev)
+if len(sys.argv) > 1 and sys.argv[1] == "gaps":
+    # how long an idle gap it takes: a burst of 60 steps, a gap, then 5 untimed and 20 timed steps (the driver's bench.py call)
+    for gap in (0.0, 0.01, 0.03, 0.1, 0.3, 1.0, 3.0, 0.0, 0.03, 0.3):
+        measure(60)
+        time.sleep(gap)
+        measure(5)
+        print("gap %5.2f s: the next 20 steps (behind 5 untimed ones) %.4f ms per step" % (gap, measure(20)), flush=True)
+    h.close()
+    sys.exit(0)
 for name, reps, gap in (("idle between", 6, 4.0), ("back to back", 0, 0.0), ("idle between", 6, 4.0)):
     if reps:
         for _ in range(reps):
