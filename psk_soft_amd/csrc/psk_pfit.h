@@ -689,8 +689,8 @@ __global__ __launch_bounds__(64) void pf_xwalk_kernel(const ChanPlan *__restrict
 
 // ---- pf_verify: grid (tiles, channels) ----
 __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restrict__ plans, const uint32_t *__restrict__ list, uint32_t ch0,
-                                                       const ChanState *__restrict__ states, const float *__restrict__ t_raw,
-                                                       float *__restrict__ t_est, PfScratch sc, int round)
+                                                       const ChanState *__restrict__ states, const float *__restrict__ yvs, uint32_t fit_cap,
+                                                       const float *__restrict__ t_raw, float *__restrict__ t_est, PfScratch sc, int round)
 {
     const uint32_t bi = list[blockIdx.y];
     const ChanPlan &p = plans[bi];
@@ -702,12 +702,12 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
     const int *k_row = sc.k + g.off;
     const float *y_row = sc.y + g.off;
     const double *S_row = sc.S + g.off;
-    const double *c_row = sc.c + g.off;
-    const float *t_row = sc.tt + g.off;
+    const float *yv = yvs + (size_t)(ch0 + bi) * fit_cap;
     double *xs_row = sc.xs + g.off;
     float *est_row = t_est + g.off;
     const uint32_t n = p.lf_n;
     const float xd = p.lf_xdelta;
+    const float sizef = (float)(p.lf_n - 1u);  // (float)yvals.size() before the push, :78
     float den_s = st.lf_den, xavg_s = st.lf_xavg;
     fit_denominator(xd, n, den_s, xavg_s);
     const FitKnown fk = fit_known(xd, n, den_s, xavg_s);
@@ -717,10 +717,21 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
         const bool valid[kR] = {i0 < g.n_out, i0 + 1 < g.n_out};
         const PfWalk *rec = sc.walk + g.bbase + c;
         const double s_c = rec->s_in;
-        const double2 cv = *reinterpret_cast<const double2 *>(c_row + i0);
-        const float2 tv = *reinterpret_cast<const float2 *>(t_row + i0);
-        const double cc[kR] = {valid[0] ? cv.x : 0.0, valid[1] ? cv.y : 0.0};
-        const double tt[kR] = {valid[0] ? (double)tv.x : 0.0, valid[1] ? (double)tv.y : 0.0};
+        // The two xySum operands of every position, formed again from ySum and y exactly as pf_ysum formed them (:70, :72, :78) --
+        // 12 bytes a symbol less to read than taking them from scratch, in a launch that is bound by its traffic; y[t - n] sits
+        // in the cache lines the block's neighbours have just read.
+        const double2 Sv = *reinterpret_cast<const double2 *>(S_row + i0);
+        const float2 y = *reinterpret_cast<const float2 *>(y_row + i0);
+        const double S_front = c ? S_row[c * kB - 1] : sc.chan[bi].ySum_c + 0.0;  // ySum after the symbol in front of the block
+        const double Sp = wave_up1(Sv.y, S_front);
+        const double z0 = valid[0] ? (double)pf_z(p, y_row, yv, fit_cap, i0) : 0.0, z1 = valid[1] ? (double)pf_z(p, y_row, yv, fit_cap, i0 + 1) : 0.0;
+        const double a0 = Sp - z0, a1 = Sv.x - z1;  // ySum after the pop, :70
+        float t0 = y.x * sizef;  // :78
+        t0 = t0 * xd;
+        float t1 = y.y * sizef;
+        t1 = t1 * xd;
+        const double cc[kR] = {valid[0] ? (double)xd * a0 : 0.0, valid[1] ? (double)xd * a1 : 0.0};  // :72
+        const double tt[kR] = {valid[0] ? (double)t0 : 0.0, valid[1] ? (double)t1 : 0.0};
         double xs[kR];
         if (rec->slow) {
             const double2 xv = *reinterpret_cast<const double2 *>(xs_row + i0);
@@ -734,13 +745,11 @@ __global__ __launch_bounds__(64) void pf_verify_kernel(const ChanPlan *__restric
         // (... and from block to block: the sum the walker carried into the next block is this block's last one, bit for bit)
         if (c + 1 < g.n_blocks && !same_bits(read_lane(xs[1], 63), rec[1].s_in))
             bad = true;
-        const double2 Sv = *reinterpret_cast<const double2 *>(S_row + i0);
         float m_;
         const float est[kR] = {fit_value_known(Sv.x, xs[0], fk, m_), fit_value_known(Sv.y, xs[1], fk, m_)};
         // the estimate fed back into the block's first symbol: the carried one, or the fit at the symbol in front of it
-        const float est_before = c ? fit_value_known(S_row[c * kB - 1], s_c, fk, m_) : st.phaseEstimate;
+        const float est_before = c ? fit_value_known(S_front, s_c, fk, m_) : st.phaseEstimate;
         const float est_prev0 = wave_up1(est[1], est_before);
-        const float2 y = *reinterpret_cast<const float2 *>(y_row + i0);
         const float2 rw = *reinterpret_cast<const float2 *>(raw_row + i0);
         const int2 k = *reinterpret_cast<const int2 *>(k_row + i0);
         // round((est_prev - raw)/2pi) == k  <=>  |est_prev - (raw + 2 pi k)| < pi: see fit_block

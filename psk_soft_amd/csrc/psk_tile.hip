@@ -936,7 +936,7 @@ hipError_t launch_pfit(const ChanPlan *plans, const uint32_t *list, uint32_t ch0
             hipLaunchKernelGGL(pf_ysum_kernel, grid, wave, 0, stream, plans, l, ch0, states, yvs, fit_cap, sc, round);
             hipLaunchKernelGGL(pf_xblock_kernel, grid, wave, 0, stream, plans, l, ch0, states, sc, round);
             hipLaunchKernelGGL(pf_xwalk_kernel, dim3(n), wave, 0, stream, plans, l, sc.blk, sc, round);
-            hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, l, ch0, states, t_raw, t_est, sc, round);
+            hipLaunchKernelGGL(pf_verify_kernel, grid, wave, 0, stream, plans, l, ch0, states, yvs, fit_cap, t_raw, t_est, sc, round);
         }
     }
     return hipGetLastError();
